@@ -1,0 +1,195 @@
+/*
+ * rc_abi.h -- C ABI of the MI355X radiance-cache ray-batch renderer.
+ *
+ * The reference (benattal/neural-radiance-caching) has no FFI: the hot path sits
+ * behind three Python call signatures.  These entry points are what
+ * a host binding for that path would bind; each one cites the reference interface it
+ * replaces (file:line relative to the reference tree).  Plain C types only: no torch,
+ * no HIP types (a stream is passed as `void*` holding a hipStream_t).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative rc_status; the message is
+ *     available through rc_last_error(); nothing aborts or throws across the ABI;
+ *   - all ray / random / output buffers are DEVICE pointers owned by the caller
+ *     (float32, row-major, leading dimension = rays); the handle owns its weight
+ *     copies and its workspace; after the first call at a given n_rays no allocation
+ *     happens inside rc_render_rays;
+ *   - work is enqueued asynchronously on the caller's stream (mirrors pmap's async
+ *     dispatch, internal/train_utils.py:3821-3830); synchronisation is the caller's;
+ *   - a handle is bound to one device and is not thread-safe.
+ */
+#ifndef RC_ABI_H_
+#define RC_ABI_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RC_ABI_VERSION 1
+#define RC_MAX_LEVELS 3
+
+typedef struct rc_handle rc_handle;
+
+typedef enum {
+  RC_OK = 0,
+  RC_ERR_INVALID_ARG = -1,
+  RC_ERR_HIP = -2,
+  RC_ERR_MISSING_WEIGHT = -3,
+  RC_ERR_SHAPE = -4,
+  RC_ERR_UNSUPPORTED = -5,
+  RC_ERR_NO_DEVICE = -6
+} rc_status;
+
+/* One multiresolution dense+hash encoding.
+ * Replaces HashEncoding's constructor fields (internal/grid_utils.py:739-805). */
+typedef struct {
+  int32_t hash_map_size;       /* T */
+  int32_t max_grid_size;       /* N_max */
+  int32_t min_grid_size;       /* N_min */
+  int32_t num_features;        /* F: 1 or 4 */
+  float bbox;                  /* bbox_scaling: cube [-bbox, bbox]^3 */
+  float precondition_scaling;  /* x10 */
+} rc_grid_config;
+
+/* Resolved render-time configuration (the values the reference takes from its gin
+ * chain; field provenance is listed in neural-radiance-caching_amd/config.py). */
+typedef struct {
+  uint32_t abi_version;        /* must be RC_ABI_VERSION */
+  int32_t num_levels;          /* proposal rounds (3) */
+  int32_t num_samples[RC_MAX_LEVELS];      /* (64, 64, 32): sampling_strategy, internal/sampling.py:53 */
+  rc_grid_config proposal_grids[RC_MAX_LEVELS];
+  rc_grid_config appearance_grid;
+  rc_grid_config material_grid;
+  rc_grid_config light_grid;
+  float anneal;                /* sampling.py:326-339 */
+  float resample_padding;
+  float raydist_p;             /* power_ladder p (secondary rays) */
+  float raydist_premult;
+  float shadow_normal_eps_dot_min;
+  float density_bias;          /* geometry.py:320 */
+  float contract_radius;       /* coord.contract_radius_2 */
+  float roughness_bias;
+  float irradiance_bias;
+  float ambient_irradiance_bias;
+  float rgb_max;
+  float slf_ambient_bias;
+  float env_rgb_bias;
+  float env_map_distance;
+  float bg_intensity;          /* VolumeIntegrator.bg_intensity_range (equal ends) */
+  float percentiles[3];        /* (5, 50, 95) */
+  int32_t num_resample;        /* 1 */
+  int32_t reserved[8];
+} rc_config;
+
+/* One named parameter tensor.  `name` is the Flax tree path
+ * ("params/Cache/Sampler/MLP_0/density_grid/grid_016", ".../density_layers_0/kernel", ...),
+ * i.e. what flax.training.checkpoints stores (internal/train_utils.py:4035-4088).
+ * Dense kernels are [in, out]. */
+typedef struct {
+  const char* name;
+  const void* data;            /* float32, contiguous */
+  int32_t ndim;
+  int64_t shape[4];
+  int32_t on_device;           /* 0: host pointer, 1: device pointer */
+} rc_tensor_desc;
+
+/* Ray batch: the fields of utils.Rays (internal/utils.py:142-169) that the path reads. */
+typedef struct {
+  const float* origins;        /* [n,3] */
+  const float* directions;     /* [n,3] */
+  const float* viewdirs;       /* [n,3] */
+  const float* near;           /* [n]   */
+  const float* far;            /* [n]   */
+  const float* lights;         /* [n,3] (light_dists extra) */
+  const float* normals;        /* [n,3] or NULL; secondary rays only (sampling.py:182-205) */
+} rc_rays;
+
+/* Explicit random inputs standing in for jax.random (threefry is not reproduced).
+ * A NULL rc_randoms*, or a NULL member, selects the reference's rng=None branch. */
+typedef struct {
+  const float* jitter[RC_MAX_LEVELS]; /* [n] U[0,1) per level: stepfun.sample single_jitter (stepfun.py:197-202) */
+  const float* gumbel;                /* [n, S_last] standard Gumbel: jax.random.categorical (models.py:242-247) */
+  const int32_t* resample_inds;       /* [n] optional: overrides the categorical draw (filtered_sampler_inds) */
+} rc_randoms;
+
+/* pass_mask bits */
+#define RC_PASS_CACHE      0x1u   /* cache-only forward (BaseNeRFModel.__call__, internal/models.py:657-774) */
+#define RC_PASS_SECONDARY  0x2u   /* is_secondary=True: far clamp, power-ladder distances, bg 0, resample, EnvMap */
+#define RC_PASS_RESAMPLE   0x4u   /* force categorical resampling to num_resample samples (models.py:193-292) */
+#define RC_PASS_NO_ENVMAP  0x8u   /* use_env_map=False for secondary rays (material.py:2191-2217) */
+
+/* Output slots: keys of the reference's `render` dict (integrator results,
+ * internal/render.py:172-247, internal/integration.py:199-231, internal/models.py:2087-2158).
+ * The `cache_<k>` keys of _finalize_outputs are aliases of these and are produced by the
+ * host layer, not by extra device buffers. */
+typedef enum {
+  RC_OUT_RGB = 0,               /* [n,3] */
+  RC_OUT_ACC,                   /* [n]   */
+  RC_OUT_DISTANCE_MEAN,         /* [n]   */
+  RC_OUT_DISTANCE_PERCENTILE_5, /* [n]   */
+  RC_OUT_DISTANCE_MEDIAN,       /* [n]   */
+  RC_OUT_DISTANCE_PERCENTILE_95,/* [n]   */
+  RC_OUT_DIFFUSE_RGB,           /* [n,3] */
+  RC_OUT_SPECULAR_RGB,
+  RC_OUT_DIRECT_RGB,            /* == ambient_rgb == direct_diffuse_rgb == ambient_diffuse_rgb (+ exact 0) */
+  RC_OUT_INDIRECT_RGB,
+  RC_OUT_ALBEDO_RGB,
+  RC_OUT_INDIRECT_DIFFUSE_RGB,
+  RC_OUT_INDIRECT_SPECULAR_RGB,
+  RC_OUT_INDIRECT_OCC,          /* [n,3] */
+  RC_OUT_MEANS,                 /* [n,3] */
+  RC_OUT_NORMALS,               /* [n,3] analytic (density gradient) */
+  RC_OUT_NORMALS_PRED,          /* [n,3] == normals_to_use */
+  RC_OUT_RAY_DISTS,             /* [n]   */
+  RC_OUT_LIGHT_DISTS,           /* [n]   */
+  RC_OUT_ENV_MAP_RGB,           /* [n,3] secondary rays only */
+  RC_OUT_RGB_NO_ENV,            /* [n,3] secondary: rgb before the EnvMap composite (rgb_no_stopgrad - env) */
+  RC_OUT_COUNT
+} rc_output_id;
+
+typedef struct {
+  float* ptr[RC_OUT_COUNT];    /* device pointers; NULL = not requested */
+} rc_outputs;
+
+/* -- lifecycle: replaces models.construct_model / model.init (internal/models.py:2323-2358) */
+int rc_create(const rc_config* cfg, int device, rc_handle** out);
+void rc_destroy(rc_handle* h);
+const char* rc_last_error(const rc_handle* h);   /* h may be NULL: last error of rc_create */
+int rc_abi_version(void);
+
+/* -- weights: replaces flax `variables` passed to model.apply (internal/train_utils.py:3796-3814)
+ * May be called several times; tensors with unknown names are rejected. */
+int rc_load_weights(rc_handle* h, const rc_tensor_desc* descs, int32_t n);
+
+/* -- the hot path: replaces model.apply(variables, rng, rays, ...)["render"] for the cache stage
+ * (BaseMaterialModel.__call__ -> BaseNeRFModel.__call__, internal/models.py:1144-1254, 657-774). */
+int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n_rays, const rc_randoms* rnd,
+                   uint32_t pass_mask, const rc_outputs* out, void* stream);
+
+/* -- single operators on the path (used by the parity tests and by the roofline bench)
+ * HashEncoding.__call__ incl. the contraction (internal/grid_utils.py:808-905, coord.py:37-69):
+ * grid_id: 0..2 proposal density grids, 3 appearance, 4 material, 5 light.
+ * points [n,3] world coordinates; features_out [n, L*F] row-major. */
+int rc_hashgrid_lookup(rc_handle* h, int32_t grid_id, const float* points, int64_t n,
+                       float* features_out, int32_t apply_contraction, void* stream);
+/* stepfun.sample_intervals (internal/stepfun.py:207-250): t [n,P+1], logits [n,P] -> out [n,S+1];
+ * jitter [n] U[0,1) or NULL. */
+int rc_sample_intervals(rc_handle* h, const float* t, const float* logits, int64_t n, int32_t num_bins,
+                        int32_t num_samples, const float* jitter, float* out, void* stream);
+
+/* -- introspection for tests / profiling: named internal buffers of the last rc_render_rays
+ * ("sdist0", "tdist2", "density1", "weights2", "shade_rgb", ...).  Returns RC_ERR_INVALID_ARG
+ * for unknown names.  count = number of float32 elements. */
+int rc_workspace_ptr(rc_handle* h, const char* name, void** ptr, int64_t* count);
+/* Per-stage device time (ms, hipEvent) of the last rc_render_rays issued with profiling on. */
+int rc_set_profiling(rc_handle* h, int32_t enabled);
+int rc_stage_count(void);
+const char* rc_stage_name(int32_t stage);
+int rc_stage_times_ms(rc_handle* h, float* out_ms, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RC_ABI_H_ */

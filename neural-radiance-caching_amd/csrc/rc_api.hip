@@ -1,0 +1,746 @@
+// C-ABI host of the radiance-cache renderer (see include/rc_abi.h).
+//
+// Owns: device copies of the hash/dense tables, the MFMA-fragment-packed MLP weights, the
+// per-batch workspace and the launch sequence that replaces BaseNeRFModel.__call__
+// (internal/models.py:657-774): 3 x [resample -> grid lookup -> density MLP] -> (categorical
+// resample) -> appearance grid -> cache shader -> volume compositing.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <array>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "rc_internal.h"
+
+void rc_launch_hashgrid_src(const RcGridDev& g, const float* points, int soa_in, const int32_t* src, int64_t n_src,
+                            int64_t n, float* out, int feature_major, int64_t ldo, float contract_radius,
+                            float* jac_out, hipStream_t stream);
+int rc_shader_lds_bytes();
+void rc_shader_prepare();
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum Stage {
+  ST_SAMPLE0 = 0, ST_GRID0, ST_MLP0, ST_SAMPLE1, ST_GRID1, ST_MLP1, ST_SAMPLE2, ST_GRID2, ST_MLP2,
+  ST_RESAMPLE, ST_GRID_APP, ST_SHADER, ST_COMPOSITE, ST_COUNT
+};
+const char* kStageNames[ST_COUNT] = {"sample0", "grid0", "mlp0", "sample1", "grid1", "mlp1", "sample2",
+                                     "grid2", "mlp2", "resample", "grid_app", "shader", "composite"};
+
+struct HostLayer {
+  std::vector<float> kernel, bias;
+  int in = 0, out = 0;
+  bool have_kernel = false, have_bias = false;
+};
+
+struct DevBuf {
+  float* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct GridState {
+  rc_grid_config cfg{};
+  std::string prefix;
+  std::vector<int> sizes;
+  std::vector<DevBuf> tables;
+  std::vector<bool> loaded;
+  RcGridDev dev{};
+};
+
+}  // namespace
+
+struct rc_handle {
+  rc_config cfg{};
+  int device = 0;
+  std::string err;
+  GridState grids[6];
+  std::map<std::string, HostLayer> layers;   // key: path without /kernel|/bias
+  bool packed_dirty = true;
+  // packed MFMA fragments (device)
+  std::map<std::string, DevBuf> packs;
+  DevBuf ide_table;
+  // workspace
+  int64_t ws_rays = 0;
+  std::map<std::string, DevBuf> ws;
+  std::map<std::string, int64_t> ws_count;
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev[ST_COUNT + 1]{};
+  bool ev_valid[ST_COUNT + 1]{};
+  bool ev_created = false;
+  float stage_ms[ST_COUNT]{};
+};
+
+namespace {
+
+#define RC_HIP(h, call)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+      return RC_ERR_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+int fail(rc_handle* h, int code, const std::string& msg) {
+  h->err = msg;
+  return code;
+}
+
+std::vector<int> grid_sizes(const rc_grid_config& g) {
+  // grid_utils.py:773-794 with scale_supersample = 1
+  const int n = 1 + (int)lround(log2((double)g.max_grid_size / g.min_grid_size));
+  std::vector<int> s;
+  for (int i = 0; i < n; ++i) s.push_back((int)lround(g.min_grid_size * pow(2.0, i)));
+  return s;
+}
+bool is_dense(const rc_grid_config& g, int n) { return (int64_t)n * n * n <= g.hash_map_size; }
+std::string level_name(const rc_grid_config& g, const std::vector<int>& sizes, int n) {
+  const int width = (int)std::to_string(sizes.back()).size();
+  std::string d = std::to_string(n);
+  while ((int)d.size() < width) d = "0" + d;
+  return std::string(is_dense(g, n) ? "grid_" : "hash_") + d;
+}
+
+void init_grid(GridState& gs, const rc_grid_config& cfg, const std::string& prefix) {
+  gs.cfg = cfg;
+  gs.prefix = prefix;
+  gs.sizes = grid_sizes(cfg);
+  gs.tables.assign(gs.sizes.size(), DevBuf{});
+  gs.loaded.assign(gs.sizes.size(), false);
+  memset(&gs.dev, 0, sizeof(gs.dev));
+  gs.dev.num_levels = (int)gs.sizes.size();
+  gs.dev.num_features = cfg.num_features;
+  gs.dev.bbox = cfg.bbox;
+  gs.dev.precondition = cfg.precondition_scaling;
+  for (size_t l = 0; l < gs.sizes.size(); ++l) {
+    const int n = gs.sizes[l];
+    RcGridLevel& L = gs.dev.lvl[l];
+    L.size = n;
+    L.dense = is_dense(cfg, n) ? 1 : 0;
+    L.entries = L.dense ? (uint32_t)n * n * n : (uint32_t)cfg.hash_map_size;
+    const uint32_t t = (uint32_t)cfg.hash_map_size;
+    L.mask = (!L.dense && (t & (t - 1)) == 0) ? t - 1 : 0;
+  }
+}
+
+// The dense layers the cache path reads: path -> (in, out).
+std::map<std::string, std::pair<int, int>> dense_inventory(const rc_config& c) {
+  std::map<std::string, std::pair<int, int>> m;
+  const int W = 64, B = 128;
+  for (int l = 0; l < c.num_levels; ++l) {
+    const std::string base = "params/Cache/Sampler/MLP_" + std::to_string(l);
+    const int K = (int)grid_sizes(c.proposal_grids[l]).size() * c.proposal_grids[l].num_features;
+    m[base + "/density_layers_0"] = {K, W};
+    m[base + "/density_layers_1"] = {W, W};
+    m[base + "/output_density_layer"] = {W, 1};
+    if (l == c.num_levels - 1) m[base + "/pred_normals_layer"] = {W, 3};
+  }
+  const std::string sh = "params/Cache/Shader";
+  const int feat = W + (int)grid_sizes(c.appearance_grid).size() * c.appearance_grid.num_features;
+  m[sh + "/bottleneck_layer"] = {feat, B};
+  m[sh + "/roughness_layer"] = {feat, 1};
+  m[sh + "/tint_layer"] = {feat, 3};
+  m[sh + "/ambient_irradiance_layer"] = {feat, 3};
+  m[sh + "/irradiance_layer"] = {feat, 3};
+  m[sh + "/integrated_brdf_layers_0"] = {B + 1, 64};
+  m[sh + "/integrated_brdf_layers_1"] = {64, 64};
+  m[sh + "/output_integrated_brdf_layer"] = {64, 1};
+  auto slf = [&](const std::string& p, int in, int w, int bott) {
+    m[p + "/layer_0"] = {in, w};
+    m[p + "/layer_1"] = {w, w};
+    m[p + "/layer_2"] = {w, w};
+    m[p + "/layer_bottleneck"] = {w + in, bott};
+    m[p + "/output_rgba_layer"] = {bott, 4};
+    m[p + "/output_ambient_rgb_layer"] = {bott, 3};
+  };
+  slf(sh + "/SurfaceLightField", B + 72, 128, 128);
+  slf(sh + "/EnvMap", 38, 128, 128);          // dead work in the reference; accepted, never read
+  slf("params/Cache/EnvMap", 27, 256, 128);
+  // material / light stages (accepted so that one checkpoint loads; used by later passes)
+  m["params/MaterialShader/bottleneck_layer"] = {32, B};
+  m["params/MaterialShader/pred_brdf_layer"] = {B, 10};
+  m["params/LightSampler/layers_0"] = {32, 64};
+  m["params/LightSampler/layers_1"] = {64, 64};
+  m["params/LightSampler/output_layer"] = {64, 640};
+  return m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA fragment packing
+// ---------------------------------------------------------------------------------------------
+struct Step { int row[2]; };               // >= 0 input row, -1 zero, -2 bias
+struct Col {
+  const HostLayer* L = nullptr;            // nullptr -> zero column
+  int col = 0;
+  int row_off = 0;
+  bool bias_ok = true;
+};
+using Tile = std::array<Col, 32>;
+
+inline int acc_feat(int t, int r, int h) { return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+void steps_natural(std::vector<Step>& s, int K, int base) {
+  for (int i = 0; i < (K + 1) / 2; ++i) s.push_back({{base + 2 * i, (2 * i + 1 < K) ? base + 2 * i + 1 : -1}});
+}
+void steps_acc(std::vector<Step>& s, int ntiles, int base) {
+  for (int t = 0; t < ntiles; ++t)
+    for (int r = 0; r < 16; ++r) s.push_back({{base + acc_feat(t, r, 0), base + acc_feat(t, r, 1)}});
+}
+void step_bias(std::vector<Step>& s) { s.push_back({{-2, -1}}); }
+
+Tile tile_full(const HostLayer* L, int t, int row_off = 0, bool bias_ok = true) {
+  Tile tl;
+  for (int i = 0; i < 32; ++i) {
+    const int c = 32 * t + i;
+    if (c < L->out) tl[i] = Col{L, c, row_off, bias_ok};
+  }
+  return tl;
+}
+// Output `regs[r]` lands in accumulator register r of BOTH half-waves.
+Tile tile_by_reg(const std::vector<Col>& regs) {
+  Tile tl;
+  for (int i = 0; i < 32; ++i) {
+    const int r = (i & 3) + 4 * (i >> 3);
+    if (r < (int)regs.size()) tl[i] = regs[r];
+  }
+  return tl;
+}
+
+std::vector<float> pack(const std::vector<Step>& steps, const std::vector<Tile>& tiles) {
+  const size_t NT = tiles.size();
+  std::vector<float> out(steps.size() * NT * 64, 0.0f);
+  for (size_t s = 0; s < steps.size(); ++s)
+    for (size_t t = 0; t < NT; ++t)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int h = lane >> 5, i = lane & 31;
+        const Col& c = tiles[t][i];
+        float v = 0.0f;
+        if (c.L) {
+          const int row = steps[s].row[h];
+          if (row == -2) {
+            if (c.bias_ok) v = c.L->bias[c.col];
+          } else if (row >= 0) {
+            const int rr = row + c.row_off;
+            if (rr < c.L->in) v = c.L->kernel[(size_t)rr * c.L->out + c.col];
+          }
+        }
+        out[(s * NT + t) * 64 + lane] = v;
+      }
+  return out;
+}
+
+int upload(rc_handle* h, const std::string& key, const std::vector<float>& v) {
+  DevBuf& b = h->packs[key];
+  if (b.bytes != v.size() * sizeof(float)) {
+    if (b.p) RC_HIP(h, hipFree(b.p));
+    RC_HIP(h, hipMalloc((void**)&b.p, v.size() * sizeof(float)));
+    b.bytes = v.size() * sizeof(float);
+  }
+  RC_HIP(h, hipMemcpy(b.p, v.data(), b.bytes, hipMemcpyHostToDevice));
+  return RC_OK;
+}
+
+// ref_utils.py:75-153 coefficient table for deg_view = 5, rounded to float32 like `mat` is.
+double fact(int n) { double f = 1; for (int i = 2; i <= n; ++i) f *= i; return f; }
+double gen_binom(double a, int k) { double p = 1; for (int j = 0; j < k; ++j) p *= (a - j); return p / fact(k); }
+double sph_coeff(int l, int m, int k) {
+  const double al = ((m & 1) ? -1.0 : 1.0) * pow(2.0, l) * fact(l) / fact(k) / fact(l - k - m) *
+                    gen_binom(0.5 * (l + k + m - 1.0), l);
+  return sqrt((2.0 * l + 1.0) * fact(l - m) / (4.0 * M_PI * fact(l + m))) * al;
+}
+void build_ide_table(RcIdeTable& tb) {
+  memset(&tb, 0, sizeof(tb));
+  int i = 0;
+  for (int d = 0; d < 5; ++d) {
+    const int l = 1 << d;
+    for (int m = 0; m <= l; ++m, ++i) {
+      tb.m[i] = m;
+      tb.sigma[i] = (float)(0.5 * l * (l + 1));
+      for (int k = 0; k <= l - m; ++k) tb.coef[i][k] = (float)sph_coeff(l, m, k);
+    }
+  }
+}
+
+const HostLayer* need(rc_handle* h, const std::string& path, std::string& missing) {
+  auto it = h->layers.find(path);
+  if (it == h->layers.end() || !it->second.have_kernel || !it->second.have_bias) {
+    if (missing.empty()) missing = path;
+    return nullptr;
+  }
+  return &it->second;
+}
+
+int repack(rc_handle* h) {
+  std::string missing;
+  const rc_config& c = h->cfg;
+  // all grids of the cache path must be loaded
+  for (int g = 0; g < 4; ++g)
+    for (size_t l = 0; l < h->grids[g].sizes.size(); ++l)
+      if (!h->grids[g].loaded[l])
+        return fail(h, RC_ERR_MISSING_WEIGHT,
+                    "missing weight: " + h->grids[g].prefix + "/" + level_name(h->grids[g].cfg, h->grids[g].sizes, h->grids[g].sizes[l]));
+  for (int l = 0; l < c.num_levels; ++l) {
+    const std::string base = "params/Cache/Sampler/MLP_" + std::to_string(l);
+    const HostLayer* d0 = need(h, base + "/density_layers_0", missing);
+    const HostLayer* d1 = need(h, base + "/density_layers_1", missing);
+    const HostLayer* dout = need(h, base + "/output_density_layer", missing);
+    const HostLayer* dn = (l == c.num_levels - 1) ? need(h, base + "/pred_normals_layer", missing) : nullptr;
+    if (!missing.empty()) return fail(h, RC_ERR_MISSING_WEIGHT, "missing weight: " + missing);
+    std::vector<Step> s;
+    steps_natural(s, d0->in, 0); step_bias(s);
+    int rc = upload(h, "d0_" + std::to_string(l), pack(s, {tile_full(d0, 0), tile_full(d0, 1)}));
+    if (rc) return rc;
+    s.clear(); steps_acc(s, 2, 0); step_bias(s);
+    rc = upload(h, "d1_" + std::to_string(l), pack(s, {tile_full(d1, 0), tile_full(d1, 1)}));
+    if (rc) return rc;
+    std::vector<Col> regs = {Col{dout, 0}};
+    if (dn) { regs.push_back(Col{dn, 0}); regs.push_back(Col{dn, 1}); regs.push_back(Col{dn, 2}); }
+    rc = upload(h, "do_" + std::to_string(l), pack(s, {tile_by_reg(regs)}));
+    if (rc) return rc;
+  }
+  const std::string sh = "params/Cache/Shader";
+  const HostLayer* bott = need(h, sh + "/bottleneck_layer", missing);
+  const HostLayer* rough = need(h, sh + "/roughness_layer", missing);
+  const HostLayer* tint = need(h, sh + "/tint_layer", missing);
+  const HostLayer* amb = need(h, sh + "/ambient_irradiance_layer", missing);
+  const HostLayer* irr = need(h, sh + "/irradiance_layer", missing);
+  const HostLayer* i0 = need(h, sh + "/integrated_brdf_layers_0", missing);
+  const HostLayer* i1 = need(h, sh + "/integrated_brdf_layers_1", missing);
+  const HostLayer* io = need(h, sh + "/output_integrated_brdf_layer", missing);
+  const std::string sl = sh + "/SurfaceLightField";
+  const HostLayer* l0 = need(h, sl + "/layer_0", missing);
+  const HostLayer* l1 = need(h, sl + "/layer_1", missing);
+  const HostLayer* l2 = need(h, sl + "/layer_2", missing);
+  const HostLayer* lb = need(h, sl + "/layer_bottleneck", missing);
+  const HostLayer* la = need(h, sl + "/output_ambient_rgb_layer", missing);
+  if (!missing.empty()) return fail(h, RC_ERR_MISSING_WEIGHT, "missing weight: " + missing);
+  int rc;
+  {
+    // heads: feature = [density feature (acc order) | appearance (natural)] + bias
+    std::vector<Step> s;
+    steps_acc(s, 2, 0); steps_natural(s, 32, 64); step_bias(s);
+    std::vector<Col> regs = {Col{rough, 0}, Col{tint, 0}, Col{tint, 1}, Col{tint, 2}, Col{amb, 0},
+                             Col{amb, 1},   Col{amb, 2},  Col{irr, 0},  Col{irr, 1},  Col{irr, 2}};
+    rc = upload(h, "heads", pack(s, {tile_full(bott, 0), tile_full(bott, 1), tile_full(bott, 2), tile_full(bott, 3),
+                                     tile_by_reg(regs)}));
+    if (rc) return rc;
+  }
+  {
+    std::vector<Step> s;
+    steps_acc(s, 4, 0); s.push_back({{128, -2}});         // (n.v | bias)
+    if ((rc = upload(h, "i0", pack(s, {tile_full(i0, 0), tile_full(i0, 1)})))) return rc;
+    s.clear(); steps_acc(s, 2, 0); step_bias(s);
+    if ((rc = upload(h, "i1", pack(s, {tile_full(i1, 0), tile_full(i1, 1)})))) return rc;
+    if ((rc = upload(h, "io", pack(s, {tile_by_reg({Col{io, 0}})})))) return rc;
+  }
+  {
+    std::vector<Step> s;
+    steps_acc(s, 4, 0);
+    for (int i = 0; i < 36; ++i) s.push_back({{128 + i, 128 + 36 + i}});   // IDE (real | imag)
+    step_bias(s);
+    rc = upload(h, "s0", pack(s, {tile_full(l0, 0), tile_full(l0, 1), tile_full(l0, 2), tile_full(l0, 3),
+                                  tile_full(lb, 0, 128), tile_full(lb, 1, 128), tile_full(lb, 2, 128),
+                                  tile_full(lb, 3, 128)}));
+    if (rc) return rc;
+    s.clear(); steps_acc(s, 4, 0); step_bias(s);
+    if ((rc = upload(h, "s1", pack(s, {tile_full(l1, 0), tile_full(l1, 1), tile_full(l1, 2), tile_full(l1, 3)})))) return rc;
+    if ((rc = upload(h, "s2", pack(s, {tile_full(l2, 0), tile_full(l2, 1), tile_full(l2, 2), tile_full(l2, 3)})))) return rc;
+    if ((rc = upload(h, "so", pack(s, {tile_by_reg({Col{la, 0}, Col{la, 1}, Col{la, 2}})})))) return rc;
+    s.clear(); steps_acc(s, 4, 0);
+    rc = upload(h, "sb", pack(s, {tile_full(lb, 0, 0, false), tile_full(lb, 1, 0, false), tile_full(lb, 2, 0, false),
+                                  tile_full(lb, 3, 0, false)}));
+    if (rc) return rc;
+  }
+  if (!h->ide_table.p) {
+    RcIdeTable tb;
+    build_ide_table(tb);
+    RC_HIP(h, hipMalloc((void**)&h->ide_table.p, sizeof(tb)));
+    h->ide_table.bytes = sizeof(tb);
+    RC_HIP(h, hipMemcpy(h->ide_table.p, &tb, sizeof(tb), hipMemcpyHostToDevice));
+  }
+  h->packed_dirty = false;
+  return RC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Workspace
+// ---------------------------------------------------------------------------------------------
+int ws_alloc(rc_handle* h, const std::string& name, int64_t count) {
+  DevBuf& b = h->ws[name];
+  const size_t bytes = (size_t)count * sizeof(float);
+  if (b.bytes < bytes) {
+    if (b.p) RC_HIP(h, hipFree(b.p));
+    RC_HIP(h, hipMalloc((void**)&b.p, bytes));
+    b.bytes = bytes;
+  }
+  h->ws_count[name] = count;
+  return RC_OK;
+}
+float* W(rc_handle* h, const std::string& name) { return h->ws[name].p; }
+
+int ensure_workspace(rc_handle* h, int64_t n) {
+  const rc_config& c = h->cfg;
+  if (n <= h->ws_rays) {
+    // counts reflect the current batch
+    for (int l = 0; l < c.num_levels; ++l) {
+      const int64_t S = c.num_samples[l];
+      const std::string L = std::to_string(l);
+      h->ws_count["sdist" + L] = n * (S + 1); h->ws_count["tdist" + L] = n * (S + 1);
+      h->ws_count["means" + L] = 3 * n * S; h->ws_count["density" + L] = n * S; h->ws_count["weights" + L] = n * S;
+    }
+    const int64_t S2 = c.num_samples[c.num_levels - 1];
+    h->ws_count["normals_pred"] = 3 * n * S2; h->ws_count["shade"] = RC_SHADE_CH * n * S2;
+    return RC_OK;
+  }
+  int rc;
+  for (int l = 0; l < c.num_levels; ++l) {
+    const int64_t S = c.num_samples[l];
+    const std::string L = std::to_string(l);
+    const int LF = h->grids[l].dev.num_levels * h->grids[l].dev.num_features;
+    if ((rc = ws_alloc(h, "sdist" + L, n * (S + 1)))) return rc;
+    if ((rc = ws_alloc(h, "tdist" + L, n * (S + 1)))) return rc;
+    if ((rc = ws_alloc(h, "means" + L, 3 * n * S))) return rc;
+    if ((rc = ws_alloc(h, "feat" + L, (int64_t)LF * n * S))) return rc;
+    if ((rc = ws_alloc(h, "density" + L, n * S))) return rc;
+    if ((rc = ws_alloc(h, "weights" + L, n * S))) return rc;
+  }
+  const int64_t S2 = c.num_samples[c.num_levels - 1];
+  const int64_t np = n * S2;
+  if ((rc = ws_alloc(h, "hbuf", ((np + 31) / 32) * 32 * 64))) return rc;
+  if ((rc = ws_alloc(h, "normals_pred", 3 * np))) return rc;
+  if ((rc = ws_alloc(h, "app", 32 * np))) return rc;
+  if ((rc = ws_alloc(h, "shade", RC_SHADE_CH * np))) return rc;
+  if ((rc = ws_alloc(h, "inds", n))) return rc;
+  if ((rc = ws_alloc(h, "src_idx", n))) return rc;
+  if ((rc = ws_alloc(h, "filt_weight", n))) return rc;
+  h->ws_rays = n;
+  return RC_OK;
+}
+
+void stage_mark(rc_handle* h, int idx, hipStream_t s) {
+  if (!h->profiling) return;
+  if (!h->ev_created) {
+    for (int i = 0; i <= ST_COUNT; ++i) (void)hipEventCreate(&h->ev[i]);
+    h->ev_created = true;
+  }
+  (void)hipEventRecord(h->ev[idx], s);
+  h->ev_valid[idx] = true;
+}
+
+__global__ void k_make_src(const int32_t* inds, int32_t* src, int64_t n, int S) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) src[r] = (int32_t)(r * S + inds[r]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rc_abi_version(void) { return RC_ABI_VERSION; }
+int rc_stage_count(void) { return ST_COUNT; }
+const char* rc_stage_name(int32_t s) { return (s >= 0 && s < ST_COUNT) ? kStageNames[s] : ""; }
+
+const char* rc_last_error(const rc_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int rc_create(const rc_config* cfg, int device, rc_handle** out) {
+  if (!cfg || !out) { g_create_error = "rc_create: null argument"; return RC_ERR_INVALID_ARG; }
+  if (cfg->abi_version != RC_ABI_VERSION) { g_create_error = "rc_create: abi_version mismatch"; return RC_ERR_INVALID_ARG; }
+  if (cfg->num_levels < 1 || cfg->num_levels > RC_MAX_LEVELS) { g_create_error = "rc_create: num_levels out of range"; return RC_ERR_INVALID_ARG; }
+  for (int l = 0; l < cfg->num_levels; ++l)
+    if (cfg->num_samples[l] < 2 || cfg->num_samples[l] > 64) { g_create_error = "rc_create: num_samples must be in [2, 64]"; return RC_ERR_UNSUPPORTED; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_error = "rc_create: no HIP device"; return RC_ERR_NO_DEVICE; }
+  if (device < 0 || device >= ndev) { g_create_error = "rc_create: bad device index"; return RC_ERR_INVALID_ARG; }
+  if (hipSetDevice(device) != hipSuccess) { g_create_error = "rc_create: hipSetDevice failed"; return RC_ERR_HIP; }
+  rc_handle* h = new rc_handle();
+  h->cfg = *cfg;
+  h->device = device;
+  const rc_grid_config* gcfgs[6] = {&cfg->proposal_grids[0], &cfg->proposal_grids[1], &cfg->proposal_grids[2],
+                                    &cfg->appearance_grid, &cfg->material_grid, &cfg->light_grid};
+  const char* prefixes[6] = {"params/Cache/Sampler/MLP_0/density_grid", "params/Cache/Sampler/MLP_1/density_grid",
+                             "params/Cache/Sampler/MLP_2/density_grid", "params/Cache/Shader/appearance_grid",
+                             "params/MaterialShader/material_grid", "params/LightSampler/light_grid"};
+  for (int g = 0; g < 6; ++g) {
+    if (gcfgs[g]->num_features != 1 && gcfgs[g]->num_features != 4) {
+      g_create_error = "rc_create: num_features must be 1 or 4";
+      delete h;
+      return RC_ERR_UNSUPPORTED;
+    }
+    if ((int)grid_sizes(*gcfgs[g]).size() > RC_MAX_GRID_LEVELS) {
+      g_create_error = "rc_create: too many grid levels";
+      delete h;
+      return RC_ERR_UNSUPPORTED;
+    }
+    init_grid(h->grids[g], *gcfgs[g], prefixes[g]);
+  }
+  // shapes the MFMA kernels are written for
+  const int K0 = h->grids[0].dev.num_levels * h->grids[0].dev.num_features;
+  const int K1 = h->grids[1].dev.num_levels * h->grids[1].dev.num_features;
+  const int K2 = h->grids[2].dev.num_levels * h->grids[2].dev.num_features;
+  const int KA = h->grids[3].dev.num_levels * h->grids[3].dev.num_features;
+  auto ks_ok = [](int K) { const int ks = (K + 1) / 2 + 1; return ks == 4 || ks == 5 || ks == 17; };
+  if (cfg->num_levels != 3 || !ks_ok(K0) || !ks_ok(K1) || K2 != 32 || KA != 32) {
+    g_create_error = "rc_create: unsupported grid feature widths (kernels are built for the hotdog/ngp_yobo shapes)";
+    delete h;
+    return RC_ERR_UNSUPPORTED;
+  }
+  *out = h;
+  return RC_OK;
+}
+
+void rc_destroy(rc_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  for (auto& g : h->grids)
+    for (auto& t : g.tables)
+      if (t.p) (void)hipFree(t.p);
+  for (auto& kv : h->packs) if (kv.second.p) (void)hipFree(kv.second.p);
+  for (auto& kv : h->ws) if (kv.second.p) (void)hipFree(kv.second.p);
+  if (h->ide_table.p) (void)hipFree(h->ide_table.p);
+  if (h->ev_created) for (int i = 0; i <= ST_COUNT; ++i) (void)hipEventDestroy(h->ev[i]);
+  delete h;
+}
+
+int rc_load_weights(rc_handle* h, const rc_tensor_desc* descs, int32_t n) {
+  if (!h) return RC_ERR_INVALID_ARG;
+  if (!descs && n > 0) return fail(h, RC_ERR_INVALID_ARG, "rc_load_weights: null descs");
+  RC_HIP(h, hipSetDevice(h->device));
+  const auto inv = dense_inventory(h->cfg);
+  for (int i = 0; i < n; ++i) {
+    const rc_tensor_desc& d = descs[i];
+    if (!d.name || !d.data) return fail(h, RC_ERR_INVALID_ARG, "rc_load_weights: null name/data");
+    const std::string name = d.name;
+    int64_t count = 1;
+    for (int k = 0; k < d.ndim; ++k) count *= d.shape[k];
+    bool handled = false;
+    // grid tables
+    for (int g = 0; g < 6 && !handled; ++g) {
+      GridState& gs = h->grids[g];
+      if (name.compare(0, gs.prefix.size() + 1, gs.prefix + "/") != 0) continue;
+      const std::string leaf = name.substr(gs.prefix.size() + 1);
+      for (size_t l = 0; l < gs.sizes.size(); ++l) {
+        if (leaf != level_name(gs.cfg, gs.sizes, gs.sizes[l])) continue;
+        const RcGridLevel& L = gs.dev.lvl[l];
+        const int64_t expect = (int64_t)L.entries * gs.cfg.num_features;
+        bool shape_ok = count == expect && d.shape[d.ndim - 1] == gs.cfg.num_features;
+        if (L.dense) shape_ok = shape_ok && d.ndim == 4 && d.shape[0] == L.size && d.shape[1] == L.size && d.shape[2] == L.size;
+        else shape_ok = shape_ok && d.ndim == 2 && d.shape[0] == gs.cfg.hash_map_size;
+        if (!shape_ok) return fail(h, RC_ERR_SHAPE, "rc_load_weights: bad shape for " + name);
+        DevBuf& b = gs.tables[l];
+        const size_t bytes = (size_t)expect * sizeof(float);
+        if (!b.p) { RC_HIP(h, hipMalloc((void**)&b.p, bytes)); b.bytes = bytes; }
+        RC_HIP(h, hipMemcpy(b.p, d.data, bytes, d.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        gs.dev.lvl[l].table = b.p;
+        gs.loaded[l] = true;
+        handled = true;
+        break;
+      }
+      if (!handled) return fail(h, RC_ERR_INVALID_ARG, "rc_load_weights: unknown grid level " + name);
+    }
+    if (handled) continue;
+    // dense layers
+    const size_t slash = name.rfind('/');
+    if (slash == std::string::npos) return fail(h, RC_ERR_INVALID_ARG, "rc_load_weights: unknown tensor " + name);
+    const std::string path = name.substr(0, slash), leaf = name.substr(slash + 1);
+    auto it = inv.find(path);
+    if (it == inv.end() || (leaf != "kernel" && leaf != "bias"))
+      return fail(h, RC_ERR_INVALID_ARG, "rc_load_weights: unknown tensor " + name);
+    HostLayer& L = h->layers[path];
+    L.in = it->second.first;
+    L.out = it->second.second;
+    std::vector<float>& dst = leaf == "kernel" ? L.kernel : L.bias;
+    if (leaf == "kernel") {
+      if (d.ndim != 2 || d.shape[0] != L.in || d.shape[1] != L.out) return fail(h, RC_ERR_SHAPE, "rc_load_weights: bad shape for " + name);
+    } else {
+      if (d.ndim != 1 || d.shape[0] != L.out) return fail(h, RC_ERR_SHAPE, "rc_load_weights: bad shape for " + name);
+    }
+    dst.resize((size_t)count);
+    if (d.on_device) RC_HIP(h, hipMemcpy(dst.data(), d.data, count * sizeof(float), hipMemcpyDeviceToHost));
+    else memcpy(dst.data(), d.data, count * sizeof(float));
+    (leaf == "kernel" ? L.have_kernel : L.have_bias) = true;
+    h->packed_dirty = true;
+  }
+  return RC_OK;
+}
+
+int rc_set_profiling(rc_handle* h, int32_t enabled) {
+  if (!h) return RC_ERR_INVALID_ARG;
+  h->profiling = enabled != 0;
+  return RC_OK;
+}
+
+int rc_stage_times_ms(rc_handle* h, float* out_ms, int32_t n) {
+  if (!h || !out_ms) return RC_ERR_INVALID_ARG;
+  if (!h->ev_created) return fail(h, RC_ERR_INVALID_ARG, "rc_stage_times_ms: profiling was not enabled");
+  RC_HIP(h, hipSetDevice(h->device));
+  RC_HIP(h, hipEventSynchronize(h->ev[ST_COUNT]));
+  for (int i = 0; i < ST_COUNT; ++i) {
+    float ms = 0.0f;
+    if (h->ev_valid[i] && h->ev_valid[i + 1]) RC_HIP(h, hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+    h->stage_ms[i] = ms;
+    if (i < n) out_ms[i] = ms;
+  }
+  return RC_OK;
+}
+
+int rc_workspace_ptr(rc_handle* h, const char* name, void** ptr, int64_t* count) {
+  if (!h || !name || !ptr || !count) return RC_ERR_INVALID_ARG;
+  auto it = h->ws.find(name);
+  if (it == h->ws.end()) return fail(h, RC_ERR_INVALID_ARG, std::string("rc_workspace_ptr: unknown buffer ") + name);
+  *ptr = it->second.p;
+  *count = h->ws_count[name];
+  return RC_OK;
+}
+
+int rc_hashgrid_lookup(rc_handle* h, int32_t grid_id, const float* points, int64_t n, float* features_out,
+                       int32_t apply_contraction, void* stream) {
+  if (!h) return RC_ERR_INVALID_ARG;
+  if (grid_id < 0 || grid_id >= 6) return fail(h, RC_ERR_INVALID_ARG, "rc_hashgrid_lookup: bad grid_id");
+  if (n < 0 || (n > 0 && (!points || !features_out))) return fail(h, RC_ERR_INVALID_ARG, "rc_hashgrid_lookup: null buffer");
+  GridState& gs = h->grids[grid_id];
+  for (size_t l = 0; l < gs.sizes.size(); ++l)
+    if (!gs.loaded[l]) return fail(h, RC_ERR_MISSING_WEIGHT, "rc_hashgrid_lookup: missing " + gs.prefix + "/" + level_name(gs.cfg, gs.sizes, gs.sizes[l]));
+  RC_HIP(h, hipSetDevice(h->device));
+  const int LF = gs.dev.num_levels * gs.dev.num_features;
+  rc_launch_hashgrid(gs.dev, points, 0, n, features_out, 0, LF, apply_contraction ? h->cfg.contract_radius : 0.0f,
+                     nullptr, (hipStream_t)stream);
+  RC_HIP(h, hipGetLastError());
+  return RC_OK;
+}
+
+int rc_sample_intervals(rc_handle* h, const float* t, const float* logits, int64_t n, int32_t num_bins,
+                        int32_t num_samples, const float* jitter, float* out, void* stream) {
+  if (!h) return RC_ERR_INVALID_ARG;
+  if (num_bins < 1 || num_bins > 64 || num_samples < 2 || num_samples > 64)
+    return fail(h, RC_ERR_UNSUPPORTED, "rc_sample_intervals: bins/samples must be <= 64 (samples >= 2)");
+  if (n < 0 || (n > 0 && (!t || !logits || !out))) return fail(h, RC_ERR_INVALID_ARG, "rc_sample_intervals: null buffer");
+  RC_HIP(h, hipSetDevice(h->device));
+  rc_launch_sample_intervals(t, logits, n, num_bins, num_samples, jitter, out, (hipStream_t)stream);
+  RC_HIP(h, hipGetLastError());
+  return RC_OK;
+}
+
+int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_randoms* rnd, uint32_t pass_mask,
+                   const rc_outputs* out, void* stream_v) {
+  if (!h) return RC_ERR_INVALID_ARG;
+  if (!rays || !out) return fail(h, RC_ERR_INVALID_ARG, "rc_render_rays: null rays/outputs");
+  if (n < 0) return fail(h, RC_ERR_INVALID_ARG, "rc_render_rays: negative n_rays");
+  if (n == 0) return RC_OK;
+  if (!rays->origins || !rays->directions || !rays->viewdirs || !rays->near || !rays->far)
+    return fail(h, RC_ERR_INVALID_ARG, "rc_render_rays: origins/directions/viewdirs/near/far are required");
+  if (!(pass_mask & RC_PASS_CACHE)) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_rays: pass_mask must include RC_PASS_CACHE");
+  const bool secondary = (pass_mask & RC_PASS_SECONDARY) != 0;
+  const bool resample = secondary || (pass_mask & RC_PASS_RESAMPLE);
+  if (resample && h->cfg.num_resample != 1) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_rays: num_resample must be 1");
+  if (resample && !(rnd && (rnd->gumbel || rnd->resample_inds)))
+    return fail(h, RC_ERR_INVALID_ARG, "rc_render_rays: resampling needs rc_randoms.gumbel or .resample_inds");
+  if (secondary) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_rays: secondary pass is not available in this build");
+  RC_HIP(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream_v;
+  int rc;
+  if (h->packed_dirty && (rc = repack(h))) return rc;
+  if ((rc = ensure_workspace(h, n))) return rc;
+  rc_shader_prepare();
+  const rc_config& c = h->cfg;
+  const int NL = c.num_levels;
+
+  for (int i = 0; i <= ST_COUNT; ++i) h->ev_valid[i] = false;
+  for (int l = 0; l < NL; ++l) {
+    const std::string L = std::to_string(l), Lp = std::to_string(l - 1);
+    const int S = c.num_samples[l];
+    const int64_t np = n * S;
+    RcSampleArgs sa{};
+    sa.origins = rays->origins; sa.directions = rays->directions; sa.viewdirs = rays->viewdirs;
+    sa.near = rays->near; sa.far = rays->far; sa.normals = rays->normals; sa.n_rays = n;
+    if (l > 0) {
+      sa.prev_sdist = W(h, "sdist" + Lp); sa.prev_tdist = W(h, "tdist" + Lp); sa.prev_density = W(h, "density" + Lp);
+      sa.P = c.num_samples[l - 1];
+      sa.prev_weights = W(h, "weights" + Lp);
+    } else {
+      sa.P = 1;
+    }
+    sa.S = S;
+    sa.jitter = rnd ? rnd->jitter[l] : nullptr;
+    sa.sdist = W(h, "sdist" + L); sa.tdist = W(h, "tdist" + L); sa.means = W(h, "means" + L);
+    sa.anneal = c.anneal; sa.padding = c.resample_padding;
+    sa.secondary = secondary ? 1 : 0;
+    sa.raydist_p = c.raydist_p; sa.raydist_premult = c.raydist_premult;
+    sa.eps_dot_min = c.shadow_normal_eps_dot_min; sa.far_clamp = c.env_map_distance;
+    stage_mark(h, ST_SAMPLE0 + 3 * l, st);
+    rc_launch_sample(sa, st);
+
+    stage_mark(h, ST_GRID0 + 3 * l, st);
+    rc_launch_hashgrid(h->grids[l].dev, W(h, "means" + L), 1, np, W(h, "feat" + L), 1, np, c.contract_radius, nullptr, st);
+
+    RcDensityMlpArgs da{};
+    da.feat = W(h, "feat" + L); da.n = np; da.ld = np;
+    da.K = h->grids[l].dev.num_levels * h->grids[l].dev.num_features;
+    da.w0 = h->packs["d0_" + L].p; da.w1 = h->packs["d1_" + L].p; da.wo = h->packs["do_" + L].p;
+    da.means = W(h, "means" + L);
+    da.density_bias = c.density_bias; da.contract_radius = c.contract_radius; da.bbox = h->grids[l].cfg.bbox;
+    da.last = (l == NL - 1) ? 1 : 0;
+    da.density = W(h, "density" + L);
+    da.hbuf = da.last ? W(h, "hbuf") : nullptr;
+    da.normals_pred = da.last ? W(h, "normals_pred") : nullptr;
+    stage_mark(h, ST_MLP0 + 3 * l, st);
+    rc_launch_density_mlp(da, st);
+  }
+  const std::string LL = std::to_string(NL - 1);
+  const int S2 = c.num_samples[NL - 1];
+  const int64_t np2 = n * S2;
+  stage_mark(h, ST_RESAMPLE, st);
+  const int32_t* src = nullptr;
+  if (resample) {
+    RcResampleArgs ra{};
+    ra.n_rays = n; ra.S = S2; ra.tdist = W(h, "tdist" + LL); ra.density = W(h, "density" + LL);
+    ra.directions = rays->directions; ra.gumbel = rnd->gumbel; ra.inds_in = rnd->resample_inds;
+    ra.inds_out = (int32_t*)W(h, "inds"); ra.filt_weight = W(h, "filt_weight"); ra.weights = W(h, "weights" + LL);
+    rc_launch_resample(ra, st);
+    hipLaunchKernelGGL(k_make_src, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const int32_t*)W(h, "inds"),
+                       (int32_t*)W(h, "src_idx"), n, S2);
+    src = (const int32_t*)W(h, "src_idx");
+  }
+  const int64_t nsh = resample ? n : np2;
+  stage_mark(h, ST_GRID_APP, st);
+  rc_launch_hashgrid_src(h->grids[3].dev, W(h, "means" + LL), 1, src, np2, nsh, W(h, "app"), 1, nsh,
+                         c.contract_radius, nullptr, st);
+  stage_mark(h, ST_SHADER, st);
+  {
+    RcShaderArgs s{};
+    s.n = nsh; s.n_src = np2; s.src = src; s.samples_per_ray = resample ? 1 : S2;
+    s.hbuf = W(h, "hbuf"); s.app = W(h, "app"); s.normals_pred = W(h, "normals_pred"); s.viewdirs = rays->viewdirs;
+    s.w_heads = h->packs["heads"].p; s.w_i0 = h->packs["i0"].p; s.w_i1 = h->packs["i1"].p; s.w_io = h->packs["io"].p;
+    s.w_s0 = h->packs["s0"].p; s.w_s1 = h->packs["s1"].p; s.w_s2 = h->packs["s2"].p; s.w_sb = h->packs["sb"].p;
+    s.w_so = h->packs["so"].p; s.ide_coef = h->ide_table.p;
+    s.roughness_bias = c.roughness_bias; s.irradiance_bias = c.irradiance_bias; s.ambient_bias = c.ambient_irradiance_bias;
+    s.rgb_max = c.rgb_max; s.slf_ambient_bias = c.slf_ambient_bias;
+    s.shade = W(h, "shade");
+    rc_launch_shader(s, st);
+  }
+  stage_mark(h, ST_COMPOSITE, st);
+  {
+    RcCompositeArgs ca{};
+    ca.directions = rays->directions; ca.origins = rays->origins; ca.lights = rays->lights; ca.n_rays = n; ca.S = S2;
+    ca.tdist = W(h, "tdist" + LL); ca.density = W(h, "density" + LL); ca.means = W(h, "means" + LL);
+    ca.normals_pred = W(h, "normals_pred"); ca.normals_grad = nullptr;
+    ca.shade = W(h, "shade"); ca.Sf = resample ? 1 : S2;
+    ca.inds = resample ? (const int32_t*)W(h, "inds") : nullptr;
+    ca.filt_weight = resample ? W(h, "filt_weight") : nullptr;
+    ca.weights = W(h, "weights" + LL);
+    ca.bg = secondary ? 0.0f : c.bg_intensity;
+    ca.pct[0] = c.percentiles[0]; ca.pct[1] = c.percentiles[1]; ca.pct[2] = c.percentiles[2];
+    ca.out = *out;
+    rc_launch_composite(ca, st);
+  }
+  stage_mark(h, ST_COUNT, st);
+  RC_HIP(h, hipGetLastError());
+  return RC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+// Internal declarations shared by the gfx950 kernels and the C-ABI host (rc_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rc_abi.h"
+
+#define RC_WAVE 64
+#define RC_MAX_GRID_LEVELS 8
+
+// float32 constants the reference hard-codes (internal/math.py:24-26).
+#define RC_TINY 1.17549435e-38f
+#define RC_FMAX 3.40282347e+38f
+#define RC_EPS 1.1920929e-07f
+
+// ---------------------------------------------------------------------------------------------
+// Hash grid
+// ---------------------------------------------------------------------------------------------
+struct RcGridLevel {
+  const float* table;   // dense: [N,N,N,F] indexed [x,y,z]; hash: [T,F]
+  int32_t size;         // N
+  int32_t dense;        // 1: dense grid, 0: hash table
+  uint32_t entries;     // N^3 or T
+  uint32_t mask;        // T-1 if T is a power of two, else 0
+};
+
+struct RcGridDev {
+  RcGridLevel lvl[RC_MAX_GRID_LEVELS];
+  int32_t num_levels;
+  int32_t num_features;
+  float bbox;
+  float precondition;
+};
+
+// points: world-space [n,3] (AoS) or SoA [3][n] (soa_in != 0).  Output feature-major [L*F][ldo]
+// (feature_major != 0) or row-major [n][L*F].  contract_radius <= 0 disables the contraction.
+void rc_launch_hashgrid(const RcGridDev& g, const float* points, int soa_in, int64_t n, float* out,
+                        int feature_major, int64_t ldo, float contract_radius, float* jac_out,
+                        hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// Sampling / compositing
+// ---------------------------------------------------------------------------------------------
+struct RcSampleArgs {
+  // ray batch
+  const float* origins; const float* directions; const float* viewdirs;
+  const float* near; const float* far; const float* normals;
+  int64_t n_rays;
+  // previous level (P bins); level 0: prev_sdist == nullptr (sdist=[0,1], w=[1])
+  const float* prev_sdist;    // [n, P+1]
+  const float* prev_tdist;    // [n, P+1]
+  const float* prev_density;  // [n*P]
+  int32_t P;
+  // outputs for the previous level
+  float* prev_weights;        // [n*P] or nullptr
+  // this level
+  int32_t S;
+  const float* jitter;        // [n] or nullptr
+  float* sdist;               // [n, S+1]
+  float* tdist;               // [n, S+1]
+  float* means;               // SoA [3][n*S]
+  // constants
+  float anneal, padding;
+  int32_t secondary;          // power-ladder warp + near replacement
+  float raydist_p, raydist_premult, eps_dot_min, far_clamp;
+};
+void rc_launch_sample(const RcSampleArgs& a, hipStream_t stream);
+
+// Stand-alone stepfun.sample_intervals (parity tests): t [n,P+1], logits [n,P] -> out [n,S+1].
+void rc_launch_sample_intervals(const float* t, const float* logits, int64_t n, int P, int S,
+                                const float* jitter, float* out, hipStream_t stream);
+
+struct RcCompositeArgs {
+  const float* directions; const float* origins; const float* lights;
+  int64_t n_rays;
+  int32_t S;                  // samples of the last level
+  const float* tdist;         // [n, S+1]
+  const float* density;       // [n*S]
+  const float* means;         // SoA [3][n*S]
+  const float* normals_pred;  // SoA [3][n*S]
+  const float* normals_grad;  // SoA [3][n*S] or nullptr
+  const float* shade;         // SoA [RC_SHADE_CH][n*Sf] per shaded sample
+  int32_t Sf;                 // shaded samples per ray: S (no resampling) or 1
+  const int32_t* inds;        // [n] selected sample when Sf == 1
+  const float* filt_weight;   // [n] importance weight w/(n*p+1e-8) when Sf == 1
+  float* weights;             // [n*S] out
+  float bg;
+  float pct[3];
+  rc_outputs out;
+};
+void rc_launch_composite(const RcCompositeArgs& a, hipStream_t stream);
+
+// Categorical resampling of the last level (models.py:193-292), num_resample == 1.
+struct RcResampleArgs {
+  int64_t n_rays; int32_t S;
+  const float* tdist; const float* density; const float* directions;
+  const float* gumbel;        // [n,S] or nullptr (then inds_in must be given)
+  const int32_t* inds_in;     // [n] or nullptr
+  int32_t* inds_out;          // [n]
+  float* filt_weight;         // [n]
+  float* weights;             // [n*S] out (weights_no_filter)
+};
+void rc_launch_resample(const RcResampleArgs& a, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// MFMA MLP kernels
+// ---------------------------------------------------------------------------------------------
+// Per-sample shader outputs (SoA channel-major).
+enum { RC_SH_RGB = 0, RC_SH_AD = 3, RC_SH_ID = 6, RC_SH_IS = 9, RC_SH_TINT = 12, RC_SHADE_CH = 15 };
+
+struct RcDensityMlpArgs {
+  const float* feat;          // feature-major [K][ld]
+  int64_t n; int64_t ld;
+  int32_t K;                  // 6, 7 or 32
+  const float* w0; const float* w1; const float* wo;   // packed MFMA fragments
+  const float* means;         // SoA [3][n] (validity mask)
+  float density_bias, contract_radius, bbox;
+  int32_t last;               // 1: also write hidden feature + predicted normals
+  float* density;             // [n]
+  float* hbuf;                // [n/32][32 steps][64] hidden feature in accumulator layout
+  float* normals_pred;        // SoA [3][n]
+};
+void rc_launch_density_mlp(const RcDensityMlpArgs& a, hipStream_t stream);
+
+struct RcShaderArgs {
+  int64_t n;                  // shaded points
+  int64_t n_src;              // points of the last level (stride of the SoA inputs)
+  const int32_t* src;         // [n] source point index or nullptr (identity)
+  int32_t samples_per_ray;    // shaded samples per ray (ray = point / samples_per_ray)
+  const float* hbuf;          // hidden density feature, accumulator layout, indexed by source point
+  const float* app;           // appearance features, feature-major [32][n] (already gathered per shaded point)
+  const float* normals_pred;  // SoA [3][n_src]
+  const float* viewdirs;      // [n_rays,3]
+  const float* w_heads; const float* w_i0; const float* w_i1; const float* w_io;
+  const float* w_s0; const float* w_s1; const float* w_s2; const float* w_sb; const float* w_so;
+  const float* ide_coef;      // IDE polynomial table (device)
+  float roughness_bias, irradiance_bias, ambient_bias, rgb_max, slf_ambient_bias;
+  float* shade;               // SoA [RC_SHADE_CH][n]
+};
+void rc_launch_shader(const RcShaderArgs& a, hipStream_t stream);
+
+// Model-level EnvMap MLP on ray directions (secondary-ray background).
+struct RcEnvMapArgs {
+  int64_t n; const float* viewdirs;
+  const float* w0; const float* w1; const float* w2; const float* wb; const float* wo;
+  float rgb_bias; float* env_rgb;  // [n,3]
+};
+void rc_launch_envmap(const RcEnvMapArgs& a, hipStream_t stream);
+
+// IDE table layout (built on the host, see rc_api.hip): for deg_view 5 there are 36 (l,m)
+// terms; term i has polynomial coefficients in z of degree <= 16 and an xy power m.
+#define RC_IDE_TERMS 36
+#define RC_IDE_ZPOW 17
+struct RcIdeTable {
+  float coef[RC_IDE_TERMS][RC_IDE_ZPOW];
+  int32_t m[RC_IDE_TERMS];
+  float sigma[RC_IDE_TERMS];
+};

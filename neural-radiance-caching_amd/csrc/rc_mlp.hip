@@ -1,0 +1,365 @@
+// Dense cache MLPs on the gfx950 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+// Replaces (reference file:line):
+//   DensityMLP.run_network / convert_raw_density / pred normals   internal/geometry.py:155-168, 318-341, 467-471
+//   NeRFMLP heads, get_integrated_brdf, _predict_appearance_passive internal/nerf.py:461-482, 628-634, 940-1090
+//   SurfaceLightFieldMLP.run_surface_lightfield_network + heads    internal/surface_light_field.py:480-499, 1011-1059
+//   ref_utils.generate_ide_fn, reflect                              internal/ref_utils.py:25-42, 131-192
+//
+// Formulation.  Every layer is computed transposed, Y^T = W^T X^T, so that the 32 points of a wave
+// sit on the MFMA's N/lane axis and the features live along registers:
+//   A operand = weight fragment  (lane l: W[k = step row of half l>>5][n = 32 t + (l & 31)])
+//   B operand = activations      (lane l: X[point l & 31][k = step row of half l>>5])
+//   D         = 32 features x 32 points, lane l reg r holds feature (r&3) + 8 (r>>2) + 4 (l>>5).
+// A layer's output accumulators are therefore *already* in B-operand form for the next layer: no
+// transposes, no cross-lane traffic.  The k order inside a layer follows the accumulator layout;
+// the host packs every weight matrix into exactly that fragment order once at load time
+// (rc_api.hip), so a layer is one linear stream of 256-byte fragments.  Bias is one extra k-step
+// (B = 1 on the low half-wave), ReLU is a VALU max on the accumulators.
+// Activations are parked in a per-wave LDS slice between layers (each lane only ever re-reads what
+// it wrote itself, so no barriers are needed) which keeps the register file for accumulators and
+// the prefetched weight fragments.
+#include "rc_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWaves = 4;   // waves per workgroup; each wave owns 32 points
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+  return z;
+}
+
+// One pass over KS k-steps for NT output tiles.  wp: packed fragments [KS][NT][64]; act: this
+// lane's activation column (act[s * 64] is step s).  Double-buffered in groups of D steps.
+template <int NT, int KS, int D>
+__device__ __forceinline__ void mlp_layer(const float* __restrict__ wp, const float* act, int lane,
+                                          f32x16 (&acc)[NT]) {
+  float a0[D][NT], a1[D][NT], b0[D], b1[D];
+  auto load = [&](float(&a)[D][NT], float(&b)[D], int s0) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int s = s0 + d;
+      if (s < KS) {
+        b[d] = act[s * 64];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[d][t] = wp[(s * NT + t) * 64 + lane];
+      }
+    }
+  };
+  auto comp = [&](float(&a)[D][NT], float(&b)[D], int s0) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (s0 + d < KS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][t], b[d], acc[t], 0, 0, 0);
+      }
+    }
+  };
+  load(a0, b0, 0);
+  for (int s0 = 0; s0 < KS; s0 += 2 * D) {
+    load(a1, b1, s0 + D);
+    comp(a0, b0, s0);
+    load(a0, b0, s0 + 2 * D);
+    comp(a1, b1, s0 + D);
+  }
+}
+
+// Park NT accumulator tiles as the next layer's activation steps [base, base + 16 NT).
+template <int NT, bool RELU>
+__device__ __forceinline__ void park(const f32x16 (&acc)[NT], float* act, int base) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = acc[t][r];
+      act[(base + t * 16 + r) * 64] = RELU ? fmaxf(v, 0.0f) : v;
+    }
+}
+
+__device__ __forceinline__ float softplus(float x) {
+  // jax.nn.softplus = logaddexp(x, 0) = max(x, 0) + log1p(exp(-|x|))
+  return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ void contract3(float& x, float& y, float& z, float radius) {
+  x = x / radius; y = y / radius; z = z / radius;
+  float mag = x * x + y * y + z * z;
+  mag = fmaxf(1.0f, mag);
+  const float scale = (2.0f * sqrtf(mag) - 1.0f) / mag;
+  x = scale * x; y = scale * y; z = scale * z;
+}
+
+// nan_to_num(-l2_normalize(g)) (ref_utils.py:45-72, geometry.py:460,471)
+__device__ __forceinline__ void neg_normalize(float& x, float& y, float& z) {
+  const float dsq = x * x + y * y + z * z;
+  const float inv = sqrtf(fmaxf(RC_TINY, dsq));
+  float nx = -(x / inv), ny = -(y / inv), nz = -(z / inv);
+  if (dsq < RC_TINY) { nx = 0.0f; ny = 0.0f; nz = 0.0f; }
+  auto fix = [](float v) {
+    if (v != v) return 0.0f;
+    return fminf(fmaxf(v, -RC_FMAX), RC_FMAX);
+  };
+  x = fix(nx); y = fix(ny); z = fix(nz);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Density MLP: K -> 64 -> 64 -> 1 (+ 64 -> 3 predicted normals on the last level)
+// ---------------------------------------------------------------------------------------------
+constexpr int kDensActSteps = 33;
+
+template <int KS0>   // k-steps of layer 0 including the bias step
+__global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a) {
+  __shared__ float lds[kWaves][kDensActSteps * 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
+  const int64_t p0 = tile * 32;
+  if (p0 >= a.n) return;
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t p = p0 + j;
+  const bool valid = p < a.n;
+  float* act = &lds[wave][lane];
+
+  // stage the grid features (natural k pairs) + bias step
+#pragma unroll
+  for (int s = 0; s < KS0 - 1; ++s) {
+    const int k = 2 * s + h;
+    act[s * 64] = (valid && k < a.K) ? a.feat[(int64_t)k * a.ld + p] : 0.0f;
+  }
+  act[(KS0 - 1) * 64] = h == 0 ? 1.0f : 0.0f;
+
+  f32x16 acc[2];
+  acc[0] = zero16(); acc[1] = zero16();
+  mlp_layer<2, KS0, 4>(a.w0, act, lane, acc);
+  park<2, true>(acc, act, 0);
+  act[32 * 64] = h == 0 ? 1.0f : 0.0f;
+
+  acc[0] = zero16(); acc[1] = zero16();
+  mlp_layer<2, 33, 4>(a.w1, act, lane, acc);
+  park<2, true>(acc, act, 0);
+  if (a.last && a.hbuf) {
+    // hidden feature handed to the shader in accumulator (= B operand) layout
+    float* hb = a.hbuf + tile * (32 * 64) + lane;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hb[(t * 16 + r) * 64] = fmaxf(acc[t][r], 0.0f);
+  }
+
+  f32x16 out[1];
+  out[0] = zero16();
+  mlp_layer<1, 33, 8>(a.wo, act, lane, out);
+
+  if (h == 0 && valid) {
+    // convert_raw_density (geometry.py:318-341)
+    const float raw = out[0][0];
+    float x = a.means[p], y = a.means[a.n + p], z = a.means[2 * a.n + p];
+    contract3(x, y, z, a.contract_radius);
+    const bool inside = (x > -a.bbox) & (x < a.bbox) & (y > -a.bbox) & (y < a.bbox) & (z > -a.bbox) & (z < a.bbox);
+    const float d = expf(fminf(fmaxf(raw + a.density_bias, -RC_FMAX), 70.0f));
+    a.density[p] = inside ? d : 0.0f;
+    if (a.last && a.normals_pred) {
+      float gx = out[0][1], gy = out[0][2], gz = out[0][3];
+      neg_normalize(gx, gy, gz);
+      a.normals_pred[p] = gx; a.normals_pred[a.n + p] = gy; a.normals_pred[2 * a.n + p] = gz;
+    }
+  }
+}
+
+
+// (l, m) of IDE term i for deg_view = 5: l in {1,2,4,8,16}, m = 0..l (ref_utils.py:105-115)
+__host__ __device__ constexpr int ide_l(int i) { return i < 2 ? 1 : (i < 5 ? 2 : (i < 10 ? 4 : (i < 19 ? 8 : 16))); }
+__host__ __device__ constexpr int ide_m(int i) { return i < 2 ? i : (i < 5 ? i - 2 : (i < 10 ? i - 5 : (i < 19 ? i - 10 : i - 19))); }
+
+// ---------------------------------------------------------------------------------------------
+// Cache shader
+// ---------------------------------------------------------------------------------------------
+// activation slice (steps): [0,64) bottleneck | [64,100) IDE | 100 bias(1|0) | 101 (dot|1)
+constexpr int kShActSteps = 102;
+constexpr int kStepBias = 100;
+constexpr int kStepDot = 101;
+
+__global__ __launch_bounds__(kWaves * 64) void k_cache_shader(RcShaderArgs a) {
+  extern __shared__ float lds_dyn[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
+  const int64_t p0 = tile * 32;
+  if (p0 >= a.n) return;
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t p = p0 + j;
+  const bool valid = p < a.n;
+  const int64_t pc = valid ? p : a.n - 1;
+  const int64_t q = a.src ? (int64_t)a.src[pc] : pc;       // source point of the last level
+  const int64_t ray = pc / a.samples_per_ray;
+  float* act = lds_dyn + wave * (kShActSteps * 64) + lane;
+
+  // ---- stage feature = [density feature (64, accumulator order) | appearance grid (32)] + bias
+  {
+    const float* hb = a.hbuf + (q >> 5) * (32 * 64) + (q & 31) + 32 * h;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) act[s * 64] = hb[s * 64];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) act[(32 + s) * 64] = a.app[(int64_t)(2 * s + h) * a.n + pc];
+    act[48 * 64] = h == 0 ? 1.0f : 0.0f;
+  }
+  // ---- heads: bottleneck (4 tiles, linear) + small heads tile
+  float rough, tint[3], ad[3], idf[3];
+  {
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) acc[t] = zero16();
+    mlp_layer<5, 49, 2>(a.w_heads, act, lane, acc);
+    // heads tile, by accumulator register (same on both half-waves): 0 roughness, 1-3 tint,
+    // 4-6 ambient irradiance, 7-9 irradiance
+    rough = softplus(acc[4][0] + a.roughness_bias);                       // nerf.py:633-634
+    tint[0] = sigmoidf(acc[4][1]); tint[1] = sigmoidf(acc[4][2]); tint[2] = sigmoidf(acc[4][3]);   // :976
+    const float ar[3] = {acc[4][4], acc[4][5], acc[4][6]};
+    const float ir[3] = {acc[4][7], acc[4][8], acc[4][9]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      ad[c] = fminf(fmaxf(softplus(ar[c] + a.ambient_bias), 0.0f), a.rgb_max);      // nerf.py:965-969
+      idf[c] = fminf(fmaxf(softplus(ir[c] + a.irradiance_bias), 0.0f), a.rgb_max);  // nerf.py:1008-1012
+    }
+    f32x16 bt[4] = {acc[0], acc[1], acc[2], acc[3]};
+    park<4, false>(bt, act, 0);
+  }
+  // ---- normals, n.(-v), reflection direction, IDE
+  {
+    const float nx = a.normals_pred[q], ny = a.normals_pred[a.n_src + q], nz = a.normals_pred[2 * a.n_src + q];
+    const float vx = a.viewdirs[3 * ray], vy = a.viewdirs[3 * ray + 1], vz = a.viewdirs[3 * ray + 2];
+    const float dotp = nx * (-vx) + ny * (-vy) + nz * (-vz);        // nerf.py:474
+    // reflect(-v, n) = 2 (n . -v) n - (-v)  (ref_utils.py:25-42)
+    const float rx = 2.0f * dotp * nx - (-vx), ry = 2.0f * dotp * ny - (-vy), rz = 2.0f * dotp * nz - (-vz);
+    act[kStepBias * 64] = h == 0 ? 1.0f : 0.0f;
+    act[kStepDot * 64] = h == 0 ? dotp : 1.0f;
+    // IDE (ref_utils.py:155-190): low half-wave keeps real parts, high half-wave imaginary parts.
+    const RcIdeTable* tb = reinterpret_cast<const RcIdeTable*>(a.ide_coef);
+    float zp[RC_IDE_ZPOW];
+    zp[0] = 1.0f;
+#pragma unroll
+    for (int k = 1; k < RC_IDE_ZPOW; ++k) zp[k] = zp[k - 1] * rz;
+    float cpw[RC_IDE_ZPOW];   // Re or Im of (x + i y)^m for this half-wave
+    {
+      float cre = 1.0f, cim = 0.0f;
+      cpw[0] = h == 0 ? cre : cim;
+#pragma unroll
+      for (int m = 1; m < RC_IDE_ZPOW; ++m) {
+        const float nre = cre * rx - cim * ry;
+        const float nim = cre * ry + cim * rx;
+        cre = nre; cim = nim;
+        cpw[m] = h == 0 ? cre : cim;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RC_IDE_TERMS; ++i) {
+      const int l = ide_l(i), m = ide_m(i);
+      float poly = 0.0f;
+#pragma unroll
+      for (int k = 0; k < RC_IDE_ZPOW; ++k) {
+        // structurally non-zero coefficients only: k <= l - m and (l - m - k) even
+        if (k <= l - m && ((l - m - k) & 1) == 0) poly = poly + zp[k] * tb->coef[i][k];
+      }
+      const float att = expf(-(0.5f * (float)(l * (l + 1))) * rough);
+      act[(64 + i) * 64] = (cpw[m] * poly) * att;
+    }
+  }
+  // ---- SLF layer_0 (tiles 0-3) + input part of layer_bottleneck (tiles 4-7): one pass over
+  //      [bottleneck | IDE | bias]; results stay in registers while the IBRDF chain runs.
+  f32x16 s0[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) s0[t] = zero16();
+  mlp_layer<8, 101, 1>(a.w_s0, act, lane, s0);
+  // ---- integrated BRDF: (bottleneck, n.v) 129 -> 64 -> 64 -> 1 (nerf.py:461-482)
+  float ibrdf;
+  {
+    f32x16 ib[2];
+    ib[0] = zero16(); ib[1] = zero16();
+    mlp_layer<2, 64, 4>(a.w_i0, act, lane, ib);
+    mlp_layer<2, 1, 1>(a.w_i0 + 64 * 2 * 64, act + kStepDot * 64, lane, ib);   // (n.v | bias) step
+    // IDE is dead now: steps [64, 97) are scratch for the IBRDF tail
+    park<2, true>(ib, act, 64);
+    act[(64 + 32) * 64] = h == 0 ? 1.0f : 0.0f;
+    ib[0] = zero16(); ib[1] = zero16();
+    mlp_layer<2, 33, 4>(a.w_i1, act + 64 * 64, lane, ib);
+    park<2, true>(ib, act, 64);
+    f32x16 o[1];
+    o[0] = zero16();
+    mlp_layer<1, 33, 8>(a.w_io, act + 64 * 64, lane, o);
+    ibrdf = sigmoidf(o[0][0] + 1.0986123f);     // + log(3), nerf.py:481
+  }
+  // ---- SLF trunk: layer_1, layer_2, layer_bottleneck (x part accumulates onto the input part)
+  float amb[3];
+  {
+    f32x16 acc[4] = {s0[0], s0[1], s0[2], s0[3]};
+    f32x16 skip[4] = {s0[4], s0[5], s0[6], s0[7]};
+    park<4, true>(acc, act, 0);
+    act[64 * 64] = h == 0 ? 1.0f : 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = zero16();
+    mlp_layer<4, 65, 2>(a.w_s1, act, lane, acc);
+    park<4, true>(acc, act, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = zero16();
+    mlp_layer<4, 65, 2>(a.w_s2, act, lane, acc);
+    park<4, true>(acc, act, 0);
+    mlp_layer<4, 64, 2>(a.w_sb, act, lane, skip);
+    park<4, true>(skip, act, 0);
+    f32x16 o[1];
+    o[0] = zero16();
+    mlp_layer<1, 65, 8>(a.w_so, act, lane, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) amb[c] = fmaxf(softplus(o[0][c] + a.slf_ambient_bias), 0.0f);   // slf.py:1053-1059
+  }
+  // ---- combine (nerf.py:1034-1053); ambient_specular is an exact 0 (ref_acc == 1)
+  if (h == 0 && valid) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float is = fminf(fmaxf(tint[c] * ibrdf * (amb[c] * 1.0f), 0.0f), a.rgb_max);
+      const float ambient = ad[c] + 0.0f;
+      const float indirect = idf[c] + is;
+      a.shade[(int64_t)(RC_SH_RGB + c) * a.n + p] = ambient + indirect;
+      a.shade[(int64_t)(RC_SH_AD + c) * a.n + p] = ad[c];
+      a.shade[(int64_t)(RC_SH_ID + c) * a.n + p] = idf[c];
+      a.shade[(int64_t)(RC_SH_IS + c) * a.n + p] = is;
+      a.shade[(int64_t)(RC_SH_TINT + c) * a.n + p] = tint[c];
+    }
+  }
+}
+
+}  // namespace
+
+void rc_launch_density_mlp(const RcDensityMlpArgs& a, hipStream_t stream) {
+  if (a.n <= 0) return;
+  const int64_t tiles = (a.n + 31) / 32;
+  dim3 grid((unsigned)((tiles + kWaves - 1) / kWaves)), block(kWaves * 64);
+  const int ks0 = (a.K + 1) / 2 + 1;
+  switch (ks0) {
+    case 4: hipLaunchKernelGGL(k_density_mlp<4>, grid, block, 0, stream, a); break;
+    case 5: hipLaunchKernelGGL(k_density_mlp<5>, grid, block, 0, stream, a); break;
+    case 17: hipLaunchKernelGGL(k_density_mlp<17>, grid, block, 0, stream, a); break;
+    default: break;   // rejected by the host before getting here
+  }
+}
+
+int rc_shader_lds_bytes() { return kWaves * kShActSteps * 64 * (int)sizeof(float); }
+
+// The shader's per-wave activation slices exceed the default 64 KiB dynamic-LDS limit.
+void rc_shader_prepare() {
+  static bool done = false;
+  if (done) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_shader),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, rc_shader_lds_bytes());
+  done = true;
+}
+
+void rc_launch_shader(const RcShaderArgs& a, hipStream_t stream) {
+  if (a.n <= 0) return;
+  const int64_t tiles = (a.n + 31) / 32;
+  dim3 grid((unsigned)((tiles + kWaves - 1) / kWaves)), block(kWaves * 64);
+  hipLaunchKernelGGL(k_cache_shader, grid, block, rc_shader_lds_bytes(), stream, a);
+}

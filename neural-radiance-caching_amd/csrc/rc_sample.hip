@@ -1,0 +1,475 @@
+// Per-ray kernels: proposal resampling, alpha weights, categorical resampling, volume compositing.
+// One 64-lane wavefront per ray: lanes are histogram bins / samples, wave scans give the CDF and
+// the transmittance, a per-wave LDS slice holds the step function.
+//
+// Replaces (reference file:line):
+//   stepfun.sample_intervals / sample / invert_cdf / integrate_weights   internal/stepfun.py:125-250
+//   math.sorted_lookup / sorted_interp                                   internal/math.py:412-457
+//   coord.construct_ray_warps, math.power_ladder / inv_power_ladder      internal/coord.py:223-260, math.py:295-341
+//   render.cast_rays (means), render.compute_alpha_weights               internal/render.py:26-169
+//   the near replacement of secondary rays                               internal/sampling.py:182-205
+//   Model.maybe_resample                                                 internal/models.py:193-292
+//   VolumeIntegrator / render.volumetric_rendering / weighted_percentile internal/integration.py:112-289,
+//                                                                        internal/render.py:172-247, stepfun.py:306-314
+#include "rc_internal.h"
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kMaxBins = 64;          // P, S <= 64
+constexpr int kSlots = kMaxBins + 1;  // fence posts
+
+__device__ __forceinline__ float wave_scan_incl(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float t = __shfl_up(v, d, 64);
+    if (lane >= d) v = v + t;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = v + __shfl_xor(v, d, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+
+__device__ __forceinline__ float safe_log(float x) { return logf(fminf(fmaxf(x, RC_TINY), RC_FMAX)); }
+
+// math.power_ladder for finite p not in {0,1} (math.py:295-316)
+__device__ __forceinline__ float power_ladder(float x, float p, float premult) {
+  x = x * premult;
+  const float xp = fabsf(x);
+  const float xs = xp / fmaxf(RC_TINY, fabsf(p - 1.0f));
+  float y = fabsf(p - 1.0f) / p * (powf(xs + 1.0f, p) - 1.0f);
+  y = fminf(fmaxf(y, -RC_FMAX), RC_FMAX);
+  return x < 0.0f ? -y : y;
+}
+// math.inv_power_ladder (math.py:319-341); y_max = minus_eps((p-1)/p) for p < 0.
+__device__ __forceinline__ float inv_power_ladder(float y, float p, float premult, float y_max) {
+  float yp = fabsf(y);
+  if (p < 0.0f) yp = fminf(fmaxf(yp, -y_max), y_max);
+  const float pm1 = fabsf(p - 1.0f);
+  float x = pm1 * (powf((p / pm1) * yp + 1.0f, 1.0f / p) - 1.0f);
+  x = y < 0.0f ? -x : x;
+  return x / premult;
+}
+
+// Alpha-compositing weights of one ray; lane i < S owns interval i.  Returns w, and (by ref) dd.
+__device__ __forceinline__ float alpha_weight(float density, float t0, float t1, float dnorm, bool active, int lane) {
+  // render.py:143-168: delta = (t1-t0)*||d||; dd = density*|delta|; alpha = 1-exp(-dd); T = exp(-excl cumsum)
+  const float dd = active ? density * fabsf((t1 - t0) * dnorm) : 0.0f;
+  const float incl = wave_scan_incl(dd, lane);
+  float excl = __shfl_up(incl, 1, 64);
+  if (lane == 0) excl = 0.0f;
+  const float alpha = 1.0f - expf(-dd);
+  const float trans = expf(-excl);
+  return active ? alpha * trans : 0.0f;
+}
+
+// Number of entries of s[0..m-1] (sorted ascending) that are <= x  (searchsorted side='right').
+__device__ __forceinline__ int upper_bound(const float* s, int m, float x) {
+  int lo = 0, hi = m;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (s[mid] <= x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+struct USpec { float start, stop, max_jitter; };
+
+// stepfun.sample_intervals on one wave.  s_t/s_cw: LDS [P+1]; writes sorted samples to s_out[0..S].
+// w_logits: lane p < P holds the logit of bin p.
+__device__ __forceinline__ void sample_intervals_wave(float logit, int P, int S, USpec us, bool has_jitter,
+                                                      float jitter, const float* s_t, float* s_cw, float* s_c,
+                                                      float* s_v, float* s_out, int lane) {
+  // softmax (jax.nn.softmax) + integrate_weights (stepfun.py:125-144)
+  const bool binact = lane < P;
+  const float m = wave_max(binact ? logit : -INFINITY);
+  const float e = binact ? expf(logit - m) : 0.0f;
+  const float ssum = wave_sum(e);
+  const float wn = e / ssum;
+  const float incl = wave_scan_incl(wn, lane);
+  if (lane == 0) s_cw[0] = 0.0f;
+  if (lane < P - 1) s_cw[lane + 1] = fminf(1.0f, incl);
+  if (lane == 0) s_cw[P] = 1.0f;
+  __syncthreads();
+  // u (stepfun.py:186-202); linspace = start*(1-step) + stop*step, last == stop
+  if (lane < S) {
+    float u;
+    if (lane == S - 1) {
+      u = us.stop;
+    } else {
+      const float step = (float)lane / (float)(S - 1);
+      u = us.start * (1.0f - step) + us.stop * step;
+    }
+    if (has_jitter) u = u + jitter * us.max_jitter;
+    // sorted_interp (math.py:448-457)
+    const int idx = upper_bound(s_cw, P + 1, u);
+    const int i1 = min(idx, P), i0 = max(idx - 1, 0);
+    const float c0 = s_cw[i0], c1 = s_cw[i1], t0 = s_t[i0], t1 = s_t[i1];
+    const float off = fminf(fmaxf((u - c0) / fmaxf(RC_EPS * RC_EPS, c1 - c0), 0.0f), 1.0f);
+    s_c[lane] = t0 + off * (t1 - t0);
+  }
+  __syncthreads();
+  // midpoints + reflected end posts, clip to [0,1] (stepfun.py:239-248)
+  for (int e2 = lane; e2 <= S; e2 += 64) {
+    float v;
+    if (e2 == 0) {
+      const float mid0 = (s_c[1] + s_c[0]) / 2.0f;
+      v = 2.0f * s_c[0] - mid0;
+    } else if (e2 == S) {
+      const float midl = (s_c[S - 1] + s_c[S - 2]) / 2.0f;
+      v = 2.0f * s_c[S - 1] - midl;
+    } else {
+      v = (s_c[e2] + s_c[e2 - 1]) / 2.0f;
+    }
+    s_v[e2] = fminf(fmaxf(v, 0.0f), 1.0f);
+  }
+  __syncthreads();
+  // jnp.sort: exact rank sort (the input is almost sorted; ties broken by index)
+  for (int e2 = lane; e2 <= S; e2 += 64) {
+    const float v = s_v[e2];
+    int rank = 0;
+    for (int k = 0; k <= S; ++k) {
+      const float o = s_v[k];
+      rank += (o < v) || (o == v && k < e2);
+    }
+    s_out[rank] = v;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kWavesPerBlock * 64) void k_sample_level(RcSampleArgs a, USpec us, float y_max) {
+  __shared__ float lds[kWavesPerBlock][5][kSlots + 3];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  const bool ray_ok = ray < a.n_rays;
+  if (!ray_ok) ray = a.n_rays - 1;   // keep the wave alive for the block barriers; stores are masked
+  float* s_t = lds[wave][0];
+  float* s_cw = lds[wave][1];
+  float* s_c = lds[wave][2];
+  float* s_v = lds[wave][3];
+  float* s_out = lds[wave][4];
+
+  const float ox = a.origins[3 * ray], oy = a.origins[3 * ray + 1], oz = a.origins[3 * ray + 2];
+  const float dx = a.directions[3 * ray], dy = a.directions[3 * ray + 1], dz = a.directions[3 * ray + 2];
+  float near = a.near[ray], far = a.far[ray];
+  if (a.secondary) {
+    far = fminf(far, a.far_clamp);                                  // models.py:670-673
+    if (a.normals) {                                                // sampling.py:182-205
+      const float dp = a.viewdirs[3 * ray] * a.normals[3 * ray] + a.viewdirs[3 * ray + 1] * a.normals[3 * ray + 1] +
+                       a.viewdirs[3 * ray + 2] * a.normals[3 * ray + 2];
+      float off = fminf(fmaxf(a.eps_dot_min / fmaxf(dp, 1e-5f), near), far);
+      off = dp > 0.0f ? off : near;
+      near = fmaxf(near, off);
+      near = fminf(fmaxf(near, 1e-5f), far - 1e-5f);
+    }
+  }
+  const int P = a.P, S = a.S;
+
+  // --- weights of the previous level -> resampling logits (sampling.py:339)
+  float w;
+  if (a.prev_sdist == nullptr) {
+    w = 1.0f;
+    if (lane == 0) { s_t[0] = 0.0f; s_t[1] = 1.0f; }
+  } else {
+    const bool act = lane < P;
+    const float t0 = act ? a.prev_tdist[ray * (P + 1) + lane] : 0.0f;
+    const float t1 = act ? a.prev_tdist[ray * (P + 1) + lane + 1] : 0.0f;
+    const float dens = act ? a.prev_density[ray * P + lane] : 0.0f;
+    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+    w = alpha_weight(dens, t0, t1, dnorm, act, lane);
+    if (act && ray_ok && a.prev_weights) a.prev_weights[ray * P + lane] = w;
+    for (int e2 = lane; e2 <= P; e2 += 64) s_t[e2] = a.prev_sdist[ray * (P + 1) + e2];
+  }
+  const float logit = a.anneal * safe_log(w + a.padding);
+  const bool hasj = a.jitter != nullptr;
+  const float jit = hasj ? a.jitter[ray] : 0.0f;
+  __syncthreads();
+  sample_intervals_wave(logit, P, S, us, hasj, jit, s_t, s_cw, s_c, s_v, s_out, lane);
+
+  // --- s -> t (coord.py:259-260), cast (render.py:49-59, 106-131)
+  float s_near = 0.0f, s_far = 0.0f;
+  if (a.secondary) {
+    s_near = power_ladder(near, a.raydist_p, a.raydist_premult);
+    s_far = power_ladder(far, a.raydist_p, a.raydist_premult);
+  }
+  for (int e2 = lane; e2 <= S; e2 += 64) {
+    const float s = s_out[e2];
+    float t;
+    if (a.secondary) t = inv_power_ladder(s * s_far + (1.0f - s) * s_near, a.raydist_p, a.raydist_premult, y_max);
+    else t = s * far + (1.0f - s) * near;
+    s_v[e2] = t;
+    if (ray_ok) {
+      a.sdist[ray * (S + 1) + e2] = s;
+      a.tdist[ray * (S + 1) + e2] = t;
+    }
+  }
+  __syncthreads();
+  if (lane < S && ray_ok) {
+    const float t0 = s_v[lane], t1 = s_v[lane + 1];
+    const float sm = t0 + t1, d = t1 - t0;
+    const float ratio = (d * d) / fmaxf(RC_EPS * RC_EPS, 3.0f * (sm * sm) + d * d);
+    const float tm = sm * (0.5f + ratio);
+    const int64_t np = a.n_rays * S, pidx = ray * S + lane;
+    a.means[pidx] = dx * tm + ox;
+    a.means[np + pidx] = dy * tm + oy;
+    a.means[2 * np + pidx] = dz * tm + oz;
+  }
+}
+
+__global__ __launch_bounds__(kWavesPerBlock * 64) void k_sample_intervals(const float* __restrict__ t,
+                                                                            const float* __restrict__ logits, int64_t n,
+                                                                            int P, int S, const float* jitter,
+                                                                            float* __restrict__ out, USpec us) {
+  __shared__ float lds[kWavesPerBlock][5][kSlots + 3];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  const bool ok = ray < n;
+  if (!ok) ray = n - 1;
+  float* s_t = lds[wave][0];
+  for (int e2 = lane; e2 <= P; e2 += 64) s_t[e2] = t[ray * (P + 1) + e2];
+  const float logit = lane < P ? logits[ray * P + lane] : 0.0f;
+  const bool hasj = jitter != nullptr;
+  const float jit = hasj ? jitter[ray] : 0.0f;
+  __syncthreads();
+  sample_intervals_wave(logit, P, S, us, hasj, jit, s_t, lds[wave][1], lds[wave][2], lds[wave][3], lds[wave][4], lane);
+  if (ok)
+    for (int e2 = lane; e2 <= S; e2 += 64) out[ray * (S + 1) + e2] = lds[wave][4][e2];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Categorical resampling (num_resample == 1)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWavesPerBlock * 64) void k_resample(RcResampleArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (ray >= a.n_rays) return;
+  const int S = a.S;
+  const bool act = lane < S;
+  const float dx = a.directions[3 * ray], dy = a.directions[3 * ray + 1], dz = a.directions[3 * ray + 2];
+  const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float t0 = act ? a.tdist[ray * (S + 1) + lane] : 0.0f;
+  const float t1 = act ? a.tdist[ray * (S + 1) + lane + 1] : 0.0f;
+  const float dens = act ? a.density[ray * S + lane] : 0.0f;
+  const float w = alpha_weight(dens, t0, t1, dnorm, act, lane);
+  if (act) a.weights[ray * S + lane] = w;
+  // logits = safe_log(w + 0) * 1 ; probs = softmax (models.py:207-209)
+  const float logit = safe_log(w);
+  const float m = wave_max(act ? logit : -INFINITY);
+  const float e = act ? expf(logit - m) : 0.0f;
+  const float p = e / wave_sum(e);
+  int ind;
+  if (a.inds_in) {
+    ind = a.inds_in[ray];
+  } else {
+    // jax.random.categorical == argmax(logits + gumbel); first index on ties
+    float key = act ? logit + a.gumbel[ray * S + lane] : -INFINITY;
+    int best = lane;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const float ok = __shfl_xor(key, d, 64);
+      const int ob = __shfl_xor(best, d, 64);
+      if (ok > key || (ok == key && ob < best)) { key = ok; best = ob; }
+    }
+    ind = best;
+  }
+  const float wsel = __shfl(w, ind, 64), psel = __shfl(p, ind, 64);
+  if (lane == 0) {
+    a.inds_out[ray] = ind;
+    a.filt_weight[ray] = wsel / (1.0f * psel + 1e-8f);     // models.py:287-289, num_resample = 1
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Volume compositing
+// ---------------------------------------------------------------------------------------------
+// jnp.interp(x, xp, fp) on LDS arrays of length m (stepfun.weighted_percentile).
+__device__ __forceinline__ float interp1(float x, const float* xp, const float* fp, int m) {
+  int i = upper_bound(xp, m, x);
+  i = min(max(i, 1), m - 1);
+  const float df = fp[i] - fp[i - 1];
+  const float dxx = xp[i] - xp[i - 1];
+  const float delta = x - xp[i - 1];
+  const float epsilon = 1.4210855e-14f;   // np.spacing(np.finfo(np.float32).eps)
+  const bool dx0 = fabsf(dxx) <= epsilon;
+  float f = dx0 ? fp[i - 1] : fp[i - 1] + (delta / (dx0 ? 1.0f : dxx)) * df;
+  if (x < xp[0]) f = fp[0];
+  if (x > xp[m - 1]) f = fp[m - 1];
+  return f;
+}
+
+__global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeArgs a) {
+  __shared__ float lds[kWavesPerBlock][2][kSlots + 3];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  const bool ray_ok = ray < a.n_rays;
+  if (!ray_ok) ray = a.n_rays - 1;
+  float* s_t = lds[wave][0];
+  float* s_cw = lds[wave][1];
+  const int S = a.S;
+  const bool act = lane < S;
+  const int64_t np = a.n_rays * S, pidx = ray * S + (act ? lane : 0);
+  const float dx = a.directions[3 * ray], dy = a.directions[3 * ray + 1], dz = a.directions[3 * ray + 2];
+  const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+  for (int e2 = lane; e2 <= S; e2 += 64) s_t[e2] = a.tdist[ray * (S + 1) + e2];
+  __syncthreads();
+  const float t0 = act ? s_t[lane] : 1.0f, t1 = act ? s_t[lane + 1] : 1.0f;
+  const float dens = act ? a.density[pidx] : 0.0f;
+  const float wnf = alpha_weight(dens, t0, t1, dnorm, act, lane);     // weights_no_filter
+  if (act && ray_ok && a.weights) a.weights[pidx] = wnf;
+  const float acc = wave_sum(wnf);                                    // render.py:202
+
+  // Filtered weights: identical to wnf without resampling; with one resampled sample the only
+  // non-zero filtered weight sits on the selected index.
+  const bool resampled = a.Sf == 1 && a.inds != nullptr;
+  int sel = 0;
+  float w = wnf;
+  if (resampled) {
+    sel = a.inds[ray];
+    w = (lane == sel) ? a.filt_weight[ray] : 0.0f;
+  }
+  const bool contrib = act && (!resampled || lane == sel);
+  const int64_t nsh = resampled ? a.n_rays : np;
+  const int64_t sidx = resampled ? ray : pidx;
+
+  auto shade = [&](int ch) -> float { return contrib ? a.shade[(int64_t)ch * nsh + sidx] : 0.0f; };
+  auto store3 = [&](int id, float x, float y, float z) {
+    if (lane == 0 && ray_ok && a.out.ptr[id]) {
+      a.out.ptr[id][3 * ray] = x; a.out.ptr[id][3 * ray + 1] = y; a.out.ptr[id][3 * ray + 2] = z;
+    }
+  };
+  auto store1 = [&](int id, float x) {
+    if (lane == 0 && ray_ok && a.out.ptr[id]) a.out.ptr[id][ray] = x;
+  };
+
+  const float bgw = fmaxf(0.0f, 1.0f - acc) * a.bg;
+  float r[3], ad[3], idf[3], isp[3], tint[3], dif[3], ind[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v_rgb = shade(RC_SH_RGB + c), v_ad = shade(RC_SH_AD + c), v_id = shade(RC_SH_ID + c);
+    const float v_is = shade(RC_SH_IS + c), v_t = shade(RC_SH_TINT + c);
+    r[c] = wave_sum(w * v_rgb) + bgw;
+    ad[c] = wave_sum(w * v_ad);
+    idf[c] = wave_sum(w * v_id);
+    isp[c] = wave_sum(w * v_is);
+    tint[c] = wave_sum(w * v_t);
+    dif[c] = wave_sum(w * (v_ad + v_id));       // diffuse_rgb = ambient_diffuse + indirect_diffuse
+    ind[c] = wave_sum(w * (v_id + v_is));       // indirect_rgb = indirect_diffuse + indirect_specular
+  }
+  store3(RC_OUT_RGB, r[0], r[1], r[2]);
+  store3(RC_OUT_DIRECT_RGB, ad[0], ad[1], ad[2]);
+  store3(RC_OUT_INDIRECT_DIFFUSE_RGB, idf[0], idf[1], idf[2]);
+  store3(RC_OUT_INDIRECT_SPECULAR_RGB, isp[0], isp[1], isp[2]);
+  store3(RC_OUT_SPECULAR_RGB, isp[0], isp[1], isp[2]);   // ambient_specular == 0 exactly
+  store3(RC_OUT_ALBEDO_RGB, tint[0], tint[1], tint[2]);
+  store3(RC_OUT_DIFFUSE_RGB, dif[0], dif[1], dif[2]);
+  store3(RC_OUT_INDIRECT_RGB, ind[0], ind[1], ind[2]);
+  const float wsum = wave_sum(contrib ? w : 0.0f);        // indirect_occ = sum w * 1
+  store3(RC_OUT_INDIRECT_OCC, wsum, wsum, wsum);
+  store1(RC_OUT_ACC, acc);
+
+  // geometry extras (always rendered: means, normals*, ray_dists, light_dists)
+  {
+    const float mx = act ? a.means[pidx] : 0.0f, my = act ? a.means[np + pidx] : 0.0f,
+                mz = act ? a.means[2 * np + pidx] : 0.0f;
+    const float wc = contrib ? w : 0.0f;
+    store3(RC_OUT_MEANS, wave_sum(wc * mx), wave_sum(wc * my), wave_sum(wc * mz));
+    const float ox = a.origins[3 * ray], oy = a.origins[3 * ray + 1], oz = a.origins[3 * ray + 2];
+    const float rd = sqrtf((ox - mx) * (ox - mx) + (oy - my) * (oy - my) + (oz - mz) * (oz - mz));
+    store1(RC_OUT_RAY_DISTS, wave_sum(wc * rd));
+    if (a.lights) {
+      const float lx = a.lights[3 * ray], ly = a.lights[3 * ray + 1], lz = a.lights[3 * ray + 2];
+      const float ld = sqrtf((lx - mx) * (lx - mx) + (ly - my) * (ly - my) + (lz - mz) * (lz - mz));
+      store1(RC_OUT_LIGHT_DISTS, wave_sum(wc * ld));
+    }
+    if (a.normals_pred) {
+      const float nx = act ? a.normals_pred[pidx] : 0.0f, ny = act ? a.normals_pred[np + pidx] : 0.0f,
+                  nz = act ? a.normals_pred[2 * np + pidx] : 0.0f;
+      store3(RC_OUT_NORMALS_PRED, wave_sum(wc * nx), wave_sum(wc * ny), wave_sum(wc * nz));
+    }
+    if (a.normals_grad) {
+      const float nx = act ? a.normals_grad[pidx] : 0.0f, ny = act ? a.normals_grad[np + pidx] : 0.0f,
+                  nz = act ? a.normals_grad[2 * np + pidx] : 0.0f;
+      store3(RC_OUT_NORMALS, wave_sum(wc * nx), wave_sum(wc * ny), wave_sum(wc * nz));
+    }
+  }
+
+  // distances (render.py:227-245) always use weights_no_filter
+  {
+    const float tmid = 0.5f * (t0 + t1);
+    const float e = wave_sum(act ? wnf * logf(tmid) : 0.0f) / fmaxf(RC_EPS, acc);
+    float dm = expf(e);
+    if (dm != dm) dm = INFINITY;                 // nan_to_num(nan=inf)
+    dm = fminf(dm, RC_FMAX);                     // +inf -> finfo.max
+    dm = fminf(fmaxf(dm, s_t[0]), s_t[S]);
+    store1(RC_OUT_DISTANCE_MEAN, dm);
+    const float wn = wnf / fmaxf(RC_EPS, acc);
+    const float incl = wave_scan_incl(wn, lane);
+    if (lane == 0) s_cw[0] = 0.0f;
+    if (lane < S - 1) s_cw[lane + 1] = fminf(1.0f, incl);
+    if (lane == 0) s_cw[S] = 1.0f;
+    __syncthreads();
+    if (lane < 3 && ray_ok) {
+      const float ps = a.pct[lane] / 100.0f;
+      const float v = interp1(ps, s_cw, s_t, S + 1);
+      const int id = lane == 0 ? RC_OUT_DISTANCE_PERCENTILE_5 : (lane == 1 ? RC_OUT_DISTANCE_MEDIAN : RC_OUT_DISTANCE_PERCENTILE_95);
+      if (a.out.ptr[id]) a.out.ptr[id][ray] = v;
+    }
+  }
+}
+
+USpec make_uspec(int S, bool has_jitter) {
+  // stepfun.py:186-202: Python-float (double) arithmetic rounded to float32 on use.
+  const double eps = (double)RC_EPS;
+  USpec u;
+  if (!has_jitter) {
+    const double pad = 1.0 / (2.0 * S);
+    u.start = (float)pad;
+    u.stop = (float)(1.0 - pad - eps);
+    u.max_jitter = 0.0f;
+  } else {
+    const double u_max = eps + (1.0 - eps) / S;
+    u.start = 0.0f;
+    u.stop = (float)(1.0 - u_max);
+    u.max_jitter = (float)((1.0 - u_max) / (S - 1) - eps);
+  }
+  return u;
+}
+
+}  // namespace
+
+void rc_launch_sample(const RcSampleArgs& a, hipStream_t stream) {
+  if (a.n_rays <= 0) return;
+  const USpec us = make_uspec(a.S, a.jitter != nullptr);
+  float y_max = 0.0f;
+  if (a.raydist_p < 0.0f) y_max = nextafterf((a.raydist_p - 1.0f) / a.raydist_p, -INFINITY);
+  dim3 grid((unsigned)((a.n_rays + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);
+  hipLaunchKernelGGL(k_sample_level, grid, block, 0, stream, a, us, y_max);
+}
+
+void rc_launch_sample_intervals(const float* t, const float* logits, int64_t n, int P, int S, const float* jitter,
+                                float* out, hipStream_t stream) {
+  if (n <= 0) return;
+  const USpec us = make_uspec(S, jitter != nullptr);
+  dim3 grid((unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);
+  hipLaunchKernelGGL(k_sample_intervals, grid, block, 0, stream, t, logits, n, P, S, jitter, out, us);
+}
+
+void rc_launch_resample(const RcResampleArgs& a, hipStream_t stream) {
+  if (a.n_rays <= 0) return;
+  dim3 grid((unsigned)((a.n_rays + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);
+  hipLaunchKernelGGL(k_resample, grid, block, 0, stream, a);
+}
+
+void rc_launch_composite(const RcCompositeArgs& a, hipStream_t stream) {
+  if (a.n_rays <= 0) return;
+  dim3 grid((unsigned)((a.n_rays + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);
+  hipLaunchKernelGGL(k_composite, grid, block, 0, stream, a);
+}

@@ -1,0 +1,327 @@
+"""ctypes binding of the C ABI in include/rc_abi.h (librc_hip.so).
+
+This is the reference-side binding a maintainer would add: plain pointers and sizes,
+no torch types cross the boundary.  torch is used only for device memory and streams.
+The product path fails loudly when the HIP library is missing -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Iterable, Optional
+
+import numpy as np
+
+from .config import GridConfig, RenderConfig
+
+RC_ABI_VERSION = 1
+RC_MAX_LEVELS = 3
+
+RC_PASS_CACHE = 0x1
+RC_PASS_SECONDARY = 0x2
+RC_PASS_RESAMPLE = 0x4
+RC_PASS_NO_ENVMAP = 0x8
+
+# rc_output_id -> (name, width); order must match include/rc_abi.h
+OUTPUTS = (
+    ("rgb", 3), ("acc", 1), ("distance_mean", 1), ("distance_percentile_5", 1), ("distance_median", 1),
+    ("distance_percentile_95", 1), ("diffuse_rgb", 3), ("specular_rgb", 3), ("direct_rgb", 3),
+    ("indirect_rgb", 3), ("albedo_rgb", 3), ("indirect_diffuse_rgb", 3), ("indirect_specular_rgb", 3),
+    ("indirect_occ", 3), ("means", 3), ("normals", 3), ("normals_pred", 3), ("ray_dists", 1),
+    ("light_dists", 1), ("env_map_rgb", 3), ("rgb_no_env", 3),
+)
+OUTPUT_ID = {name: i for i, (name, _) in enumerate(OUTPUTS)}
+RC_OUT_COUNT = len(OUTPUTS)
+
+
+class rc_grid_config(C.Structure):
+    _fields_ = [("hash_map_size", C.c_int32), ("max_grid_size", C.c_int32), ("min_grid_size", C.c_int32),
+                ("num_features", C.c_int32), ("bbox", C.c_float), ("precondition_scaling", C.c_float)]
+
+
+class rc_config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("num_levels", C.c_int32), ("num_samples", C.c_int32 * RC_MAX_LEVELS),
+        ("proposal_grids", rc_grid_config * RC_MAX_LEVELS), ("appearance_grid", rc_grid_config),
+        ("material_grid", rc_grid_config), ("light_grid", rc_grid_config),
+        ("anneal", C.c_float), ("resample_padding", C.c_float), ("raydist_p", C.c_float),
+        ("raydist_premult", C.c_float), ("shadow_normal_eps_dot_min", C.c_float), ("density_bias", C.c_float),
+        ("contract_radius", C.c_float), ("roughness_bias", C.c_float), ("irradiance_bias", C.c_float),
+        ("ambient_irradiance_bias", C.c_float), ("rgb_max", C.c_float), ("slf_ambient_bias", C.c_float),
+        ("env_rgb_bias", C.c_float), ("env_map_distance", C.c_float), ("bg_intensity", C.c_float),
+        ("percentiles", C.c_float * 3), ("num_resample", C.c_int32), ("reserved", C.c_int32 * 8),
+    ]
+
+
+class rc_tensor_desc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32), ("shape", C.c_int64 * 4),
+                ("on_device", C.c_int32)]
+
+
+class rc_rays(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("origins", "directions", "viewdirs", "near", "far", "lights", "normals")]
+
+
+class rc_randoms(C.Structure):
+    _fields_ = [("jitter", C.c_void_p * RC_MAX_LEVELS), ("gumbel", C.c_void_p), ("resample_inds", C.c_void_p)]
+
+
+class rc_outputs(C.Structure):
+    _fields_ = [("ptr", C.c_void_p * RC_OUT_COUNT)]
+
+
+EXPORTS = (
+    "rc_create", "rc_destroy", "rc_last_error", "rc_abi_version", "rc_load_weights", "rc_render_rays",
+    "rc_hashgrid_lookup", "rc_sample_intervals", "rc_workspace_ptr", "rc_set_profiling", "rc_stage_count",
+    "rc_stage_name", "rc_stage_times_ms",
+)
+
+_LIB = None
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "librc_hip.so")
+
+
+def load_library():
+    """dlopen librc_hip.so.  Raises (never falls back) when it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the render path.")
+    lib = C.CDLL(path)
+    lib.rc_create.argtypes = [C.POINTER(rc_config), C.c_int, C.POINTER(C.c_void_p)]
+    lib.rc_create.restype = C.c_int
+    lib.rc_destroy.argtypes = [C.c_void_p]
+    lib.rc_destroy.restype = None
+    lib.rc_last_error.argtypes = [C.c_void_p]
+    lib.rc_last_error.restype = C.c_char_p
+    lib.rc_abi_version.restype = C.c_int
+    lib.rc_load_weights.argtypes = [C.c_void_p, C.POINTER(rc_tensor_desc), C.c_int32]
+    lib.rc_load_weights.restype = C.c_int
+    lib.rc_render_rays.argtypes = [C.c_void_p, C.POINTER(rc_rays), C.c_int64, C.POINTER(rc_randoms), C.c_uint32,
+                                   C.POINTER(rc_outputs), C.c_void_p]
+    lib.rc_render_rays.restype = C.c_int
+    lib.rc_hashgrid_lookup.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.rc_hashgrid_lookup.restype = C.c_int
+    lib.rc_sample_intervals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rc_sample_intervals.restype = C.c_int
+    lib.rc_workspace_ptr.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    lib.rc_workspace_ptr.restype = C.c_int
+    lib.rc_set_profiling.argtypes = [C.c_void_p, C.c_int32]
+    lib.rc_set_profiling.restype = C.c_int
+    lib.rc_stage_count.restype = C.c_int
+    lib.rc_stage_name.argtypes = [C.c_int32]
+    lib.rc_stage_name.restype = C.c_char_p
+    lib.rc_stage_times_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int32]
+    lib.rc_stage_times_ms.restype = C.c_int
+    _LIB = lib
+    return lib
+
+
+def _grid_c(g: GridConfig) -> rc_grid_config:
+    return rc_grid_config(g.hash_map_size, g.max_grid_size, g.min_grid_size, g.num_features, g.bbox,
+                          g.precondition_scaling)
+
+
+def config_to_c(cfg: RenderConfig) -> rc_config:
+    c = rc_config()
+    c.abi_version = RC_ABI_VERSION
+    c.num_levels = cfg.num_levels
+    for i, (_, _, n) in enumerate(cfg.sampling_strategy):
+        c.num_samples[i] = n
+        c.proposal_grids[i] = _grid_c(cfg.proposal_grids[i])
+    c.appearance_grid = _grid_c(cfg.appearance_grid)
+    c.material_grid = _grid_c(cfg.material_grid)
+    c.light_grid = _grid_c(cfg.light_grid)
+    for k in ("anneal", "resample_padding", "raydist_p", "raydist_premult", "shadow_normal_eps_dot_min",
+              "density_bias", "contract_radius", "roughness_bias", "irradiance_bias", "ambient_irradiance_bias",
+              "rgb_max", "slf_ambient_bias", "env_rgb_bias", "env_map_distance"):
+        setattr(c, k, float(getattr(cfg, k)))
+    c.bg_intensity = float(cfg.bg_intensity)
+    for i, p in enumerate(cfg.percentiles):
+        c.percentiles[i] = float(p)
+    c.num_resample = cfg.num_resample
+    return c
+
+
+class RcError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"rc error {code}: {msg}")
+        self.code = code
+
+
+class RadianceCache:
+    """One rc_handle: the cache renderer bound to one GPU."""
+
+    def __init__(self, cfg: RenderConfig, device: int = 0):
+        import torch  # device memory / streams only
+
+        self._torch = torch
+        self.lib = load_library()
+        self.cfg = cfg
+        self.device = device
+        self._h = C.c_void_p()
+        ccfg = config_to_c(cfg)
+        rc = self.lib.rc_create(C.byref(ccfg), device, C.byref(self._h))
+        if rc != 0:
+            raise RcError(rc, (self.lib.rc_last_error(None) or b"").decode())
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.rc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise RcError(rc, (self.lib.rc_last_error(self._h) or b"").decode())
+
+    # -- weights ----------------------------------------------------------------------------
+    def load_weights(self, weights: Dict[str, object]):
+        """weights: flat dict 'params/...' -> numpy array or torch tensor (float32)."""
+        torch = self._torch
+        descs = (rc_tensor_desc * len(weights))()
+        keep = []
+        for i, (name, w) in enumerate(weights.items()):
+            if isinstance(w, torch.Tensor):
+                t = w.detach().to(torch.float32).contiguous()
+                keep.append(t)
+                ptr, on_dev, shape = t.data_ptr(), int(t.is_cuda), tuple(t.shape)
+            else:
+                a = np.ascontiguousarray(w, dtype=np.float32)
+                keep.append(a)
+                ptr, on_dev, shape = a.ctypes.data, 0, a.shape
+            bname = name.encode()
+            keep.append(bname)
+            descs[i].name = bname
+            descs[i].data = ptr
+            descs[i].ndim = len(shape)
+            for k, s in enumerate(shape):
+                descs[i].shape[k] = s
+            descs[i].on_device = on_dev
+        self._check(self.lib.rc_load_weights(self._h, descs, len(weights)))
+
+    # -- hot path ---------------------------------------------------------------------------
+    def _dev(self, x, dtype=None):
+        torch = self._torch
+        dtype = dtype or torch.float32
+        if not isinstance(x, torch.Tensor):
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        return x.to(device=f"cuda:{self.device}", dtype=dtype).contiguous()
+
+    def render_rays(self, rays: Dict[str, object], randoms: Optional[Dict[str, object]] = None,
+                    pass_mask: int = RC_PASS_CACHE, outputs: Optional[Iterable[str]] = None):
+        """rays: dict with origins, directions, viewdirs [n,3], near, far [n] or [n,1], optional lights,
+        normals.  Returns dict name -> torch cuda tensor ([n,3] or [n])."""
+        torch = self._torch
+        r = rc_rays()
+        held = {}
+        n = None
+        for k in ("origins", "directions", "viewdirs", "near", "far", "lights", "normals"):
+            v = rays.get(k)
+            if v is None:
+                continue
+            t = self._dev(v)
+            t = t.reshape(-1, 3) if k not in ("near", "far") else t.reshape(-1)
+            held[k] = t
+            setattr(r, k, t.data_ptr())
+            n = t.shape[0] if n is None else n
+            if t.shape[0] != n:
+                raise ValueError(f"ray field {k} has {t.shape[0]} rows, expected {n}")
+        rnd_p = None
+        if randoms is not None:
+            rnd = rc_randoms()
+            jit = randoms.get("jitter")
+            if jit is not None:
+                for l, j in enumerate(jit):
+                    if j is not None:
+                        t = self._dev(j).reshape(-1)
+                        held[f"jit{l}"] = t
+                        rnd.jitter[l] = t.data_ptr()
+            if randoms.get("gumbel") is not None:
+                held["gumbel"] = self._dev(randoms["gumbel"])
+                rnd.gumbel = held["gumbel"].data_ptr()
+            if randoms.get("resample_inds") is not None:
+                held["inds"] = self._dev(randoms["resample_inds"], torch.int32).reshape(-1)
+                rnd.resample_inds = held["inds"].data_ptr()
+            rnd_p = C.byref(rnd)
+        names = [nm for nm, _ in OUTPUTS] if outputs is None else list(outputs)
+        out = rc_outputs()
+        res = {}
+        dev = f"cuda:{self.device}"
+        for nm in names:
+            width = OUTPUTS[OUTPUT_ID[nm]][1]
+            t = torch.zeros((n, 3) if width == 3 else (n,), dtype=torch.float32, device=dev)
+            res[nm] = t
+            out.ptr[OUTPUT_ID[nm]] = t.data_ptr()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.rc_render_rays(self._h, C.byref(r), n, rnd_p, pass_mask, C.byref(out), stream))
+        self._keep = [held]   # keep inputs alive until the next call (async enqueue)
+        return res
+
+    # -- single operators ---------------------------------------------------------------------
+    def hashgrid_lookup(self, grid_id: int, points, apply_contraction: bool = True):
+        torch = self._torch
+        g = (list(self.cfg.proposal_grids) + [self.cfg.appearance_grid, self.cfg.material_grid, self.cfg.light_grid])[grid_id]
+        p = self._dev(points).reshape(-1, 3)
+        out = torch.empty((p.shape[0], g.out_dim), dtype=torch.float32, device=p.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.rc_hashgrid_lookup(self._h, grid_id, p.data_ptr(), p.shape[0], out.data_ptr(),
+                                                int(apply_contraction), stream))
+        self._keep = [p]
+        return out
+
+    def sample_intervals(self, t, logits, num_samples: int, jitter=None):
+        torch = self._torch
+        t = self._dev(t)
+        logits = self._dev(logits)
+        n, P = logits.shape
+        out = torch.empty((n, num_samples + 1), dtype=torch.float32, device=t.device)
+        j = None if jitter is None else self._dev(jitter).reshape(-1)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.rc_sample_intervals(self._h, t.data_ptr(), logits.data_ptr(), n, P, num_samples,
+                                                 None if j is None else j.data_ptr(), out.data_ptr(), stream))
+        self._keep = [t, logits, j]
+        return out
+
+    # -- introspection ------------------------------------------------------------------------
+    def workspace(self, name: str, dtype=None):
+        """Copy of an internal buffer of the last render (tests / debugging)."""
+        torch = self._torch
+        ptr, cnt = C.c_void_p(), C.c_int64()
+        self._check(self.lib.rc_workspace_ptr(self._h, name.encode(), C.byref(ptr), C.byref(cnt)))
+        torch.cuda.synchronize(self.device)
+        host = np.empty(cnt.value, dtype=np.float32)
+        _memcpy_d2h(host.ctypes.data, ptr.value, cnt.value * 4)
+        return host.view(np.int32) if dtype == np.int32 else host
+
+    def set_profiling(self, enabled: bool):
+        self._check(self.lib.rc_set_profiling(self._h, int(enabled)))
+
+    def stage_times_ms(self) -> Dict[str, float]:
+        n = self.lib.rc_stage_count()
+        arr = (C.c_float * n)()
+        self._check(self.lib.rc_stage_times_ms(self._h, arr, n))
+        return {self.lib.rc_stage_name(i).decode(): float(arr[i]) for i in range(n)}
+
+
+def _memcpy_d2h(dst: int, src: int, nbytes: int):
+    """hipMemcpy device->host through the HIP runtime torch already loaded."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    rc = hip.hipMemcpy(dst, src, nbytes, 2)  # hipMemcpyDeviceToHost
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpy failed: {rc}")

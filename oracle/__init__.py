@@ -1,0 +1,23 @@
+"""CPU oracle for the radiance-cache ray-batch hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package
+(`neural-radiance-caching_amd/`) may import, call, link or execute anything in
+this directory.  Allowed users: `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py`, and there only as the checker / the timed CPU
+baseline -- never as the thing shipped.
+
+What this is: a restatement, in torch on the CPU, of the arithmetic of
+benattal/neural-radiance-caching's `Model.__call__` hot path.
+Every function cites the reference file:line it follows.  The same code runs in
+float64 ("spec") and float32 ("CPU baseline"); the dtype is taken from the
+inputs.
+
+PARITY UNPINNED.  The reference is pure JAX/Flax/gin and none of those
+packages exist in the build image (plain ModuleNotFoundError, no network), the
+reference ships no tests, golden vectors or fixtures for any file on this path
+(SURVEY.md §4, §8c), and it has no native sources to compile.  The oracle is
+therefore pinned only by (a) hand-computed known-answer tests of the risky
+conventions (tests/test_oracle_kat.py) and (b) fp64-vs-fp32 self-agreement.
+Randomness (jax.random / threefry) is not reproduced: every random quantity is
+an explicit input tensor.
+"""
