@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/sec of the radiance-cache forward on 1024-ray batches.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (rc_render_rays: 3 proposal rounds -> hash-grid lookups ->
+density MLPs -> cache shader -> volume compositing) over one batch of 1024 synthetic rays with
+the hotdog architecture and synthetic weights; rays, weights and outputs are resident in HBM.
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank renders its own
+1024-ray batch per step (ray batches shard trivially, no data-path collective; weak scaling) and
+the rendered pixels are all-gathered over RCCL once at the end, outside the per-step loop, exactly
+as the image renderer does once per image.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the cache shader, fp32 MFMA
+bound); its duration comes from HIP events recorded on the launch stream inside the timed region.
+`hashgrid` reports the achieved algorithmic GB/s of the four grid-lookup kernels the same way.
+`cpu_baseline` times the CPU oracle (a torch fp32 restatement of the reference path, kind "port":
+the JAX reference cannot run here) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+RAYS_PER_BATCH = 1024
+# algorithmic work per primary ray, cache-only
+GRID_BYTES = {"grid0": 64 * 192, "grid1": 64 * 224, "grid2": 32 * 1024, "grid_app": 32 * 1024}   # per ray
+SHADER_FLOP_PER_SAMPLE = 253824          # output-relevant (heads + IBRDF + SurfaceLightField MLP)
+SHADED_SAMPLES = 32
+PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(cfg, weights_np, n_rays, budget_s=20.0):
+    """Oracle (torch fp32, all host cores) on the same 1024-ray batch; bounded to ~budget_s."""
+    import numpy as np
+    import torch
+
+    import nrc_amd
+    from oracle import cache_ref
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    wt = {k: torch.from_numpy(v) for k, v in weights_np.items()}
+    rays = nrc_amd.synthetic_rays(n_rays)
+    rt = {k: torch.from_numpy(np.asarray(v)) for k, v in rays.hot_fields().items()}
+    run = lambda: cache_ref.cache_forward(wt, cfg, rt, None, want_grad_normals=True, exec_dead_envmap=True)
+    run()  # warm-up
+    times = []
+    t_end = time.time() + budget_s
+    while len(times) < 10 and (time.time() < t_end or len(times) < 2):
+        t0 = time.time()
+        run()
+        times.append(time.time() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": n_rays / med, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} timed passes of one {n_rays}-ray batch (64,64,32 samples), torch fp32 oracle "
+                      f"incl. the reference's dead cache-EnvMap MLP and autograd normals; median {med*1e3:.0f} ms"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph-mode", type=int, default=2, help="0 eager, 1 lazy hipGraph, 2 hipGraph at once")
+    ap.add_argument("--profile-mode", type=int, default=2,
+                    help="events in the timed region: 0 none, 1 every stage, 2 dominant kernel only")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import nrc_amd
+    from nrc_amd import rc_ext
+    from nrc_amd.model import _CACHE_DEVICE_KEYS
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+
+    cfg = nrc_amd.hotdog_config()
+    weights = nrc_amd.synthetic_weights(cfg)
+    rc = rc_ext.RadianceCache(cfg, local_rank)
+    rc.load_weights(weights)
+    rc.set_graph_mode(args.graph_mode)
+    rays_np = nrc_amd.synthetic_rays(RAYS_PER_BATCH, seed=20200823 + rank)
+    rays = {k: torch.from_numpy(np.asarray(v)).to(dev).contiguous() for k, v in rays_np.hot_fields().items()}
+    rays["near"] = rays["near"].reshape(-1)
+    rays["far"] = rays["far"].reshape(-1)
+    rays.pop("lossmult", None)
+
+    out = rc.render_rays(rays, None, outputs=_CACHE_DEVICE_KEYS)
+    # Timed region: two HIP events per step around the dominant kernel only (each event record costs
+    # a few us of GPU timeline, so the full per-stage profile is taken in a separate pass below).
+    rc.set_profiling(args.profile_mode)
+    for _ in range(args.warmup):
+        rc.render_rays(rays, None, out=out)
+    rc.set_profiling(args.profile_mode)          # reset the event ring
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rc.render_rays(rays, None, out=out)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # rendered pixels of all ranks, gathered once (image granularity), outside the step loop
+        pix = torch.cat([out["rgb"], out["acc"][:, None]], dim=1)
+        gathered = torch.empty((world * pix.shape[0], 4), device=dev)
+        dist.all_gather(list(gathered.chunk(world)), pix)
+    sh_ms = rc.stage_times_ms()["shader"] if args.profile_mode else float("nan")
+    # separate pass: every stage bracketed by events (not part of `value`)
+    rc.set_profiling(1)
+    for _ in range(16):
+        rc.render_rays(rays, None, out=out)
+    torch.cuda.synchronize()
+    stage = rc.stage_times_ms()
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    rays_total = RAYS_PER_BATCH * world * args.steps
+    value = rays_total / elapsed
+    flops = SHADER_FLOP_PER_SAMPLE * SHADED_SAMPLES * RAYS_PER_BATCH
+    achieved_tf = flops / (sh_ms * 1e-3) / 1e12
+    grid_ms = sum(stage[k] for k in GRID_BYTES)
+    grid_bytes = sum(GRID_BYTES.values()) * RAYS_PER_BATCH
+    grid_gbs = grid_bytes / (grid_ms * 1e-3) / 1e9
+    res = {
+        "metric": "rays/sec (1024-ray batch, 64+64 proposal + 32 shaded samples/ray), hotdog cache forward",
+        "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "hotdog cache render 1024 rays x (64,64,32) samples, cache-only passes, "
+                               "synthetic rays + synthetic weights (configs[1])",
+                   "rays_per_batch_per_gpu": RAYS_PER_BATCH, "parallelism": f"ray-sharded x{world}",
+                   "launch": "eager" if (args.profile_mode or args.graph_mode == 0) else "hipGraph"},
+        "roofline": {"kernel": "k_cache_shader", "bound": "mfma", "achieved": achieved_tf,
+                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
+                     "traffic": None, "avg_launch_ms": sh_ms,
+                     "algorithmic_flop_per_launch": flops},
+        "hashgrid": {"kernels": "k_hashgrid_fwd x4 (grid0, grid1, grid2, grid_app)", "bound": "hbm",
+                     "achieved": grid_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": grid_gbs / PEAK_HBM_GBS,
+                     "sum_launch_ms": grid_ms, "algorithmic_bytes_per_batch": grid_bytes},
+        "stage_ms_separate_pass": stage,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        res["cpu_baseline"] = cpu_baseline(cfg, weights, RAYS_PER_BATCH)
+    else:
+        res["cpu_baseline"] = None
+    print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -183,8 +183,14 @@ int rc_sample_intervals(rc_handle* h, const float* t, const float* logits, int64
  * ("sdist0", "tdist2", "density1", "weights2", "shade_rgb", ...).  Returns RC_ERR_INVALID_ARG
  * for unknown names.  count = number of float32 elements. */
 int rc_workspace_ptr(rc_handle* h, const char* name, void** ptr, int64_t* count);
-/* Per-stage device time (ms, hipEvent) of the last rc_render_rays issued with profiling on. */
-int rc_set_profiling(rc_handle* h, int32_t enabled);
+/* Per-stage device time (ms, hipEvents recorded on the launch stream), averaged over the calls
+ * issued since profiling was last (re)enabled (ring of 16).  mode 0 off, 1 every stage,
+ * 2 only the dominant kernel (cache shader; two events per call).  Profiled calls launch eagerly. */
+int rc_set_profiling(rc_handle* h, int32_t mode);
+/* Launch mode of rc_render_rays: 0 = eager kernel launches, 1 = capture a hipGraph the second time
+ * an identical call (same sizes and pointers) is seen and replay it afterwards (default),
+ * 2 = capture on first sight. */
+int rc_set_graph_mode(rc_handle* h, int32_t mode);
 int rc_stage_count(void);
 const char* rc_stage_name(int32_t stage);
 int rc_stage_times_ms(rc_handle* h, float* out_ms, int32_t n);

@@ -19,6 +19,7 @@ void rc_launch_hashgrid_src(const RcGridDev& g, const float* points, int soa_in,
                             int64_t n, float* out, int feature_major, int64_t ldo, float contract_radius,
                             float* jac_out, hipStream_t stream);
 int rc_shader_lds_bytes();
+int rc_weight_chunk_floats();
 void rc_shader_prepare();
 
 namespace {
@@ -41,6 +42,20 @@ struct HostLayer {
 struct DevBuf {
   float* p = nullptr;
   size_t bytes = 0;
+};
+
+constexpr int kEvSlots = 16;
+
+// Everything that is baked into the kernel arguments of one rc_render_rays call.
+struct RenderKey {
+  int64_t n; uint32_t mask; int slot;
+  const void* rays[7]; const void* rnd[RC_MAX_LEVELS + 2]; const void* out[RC_OUT_COUNT];
+  bool operator==(const RenderKey& o) const { return memcmp(this, &o, sizeof(RenderKey)) == 0; }
+};
+struct GraphEntry {
+  RenderKey key;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
 };
 
 struct GridState {
@@ -68,12 +83,19 @@ struct rc_handle {
   int64_t ws_rays = 0;
   std::map<std::string, DevBuf> ws;
   std::map<std::string, int64_t> ws_count;
-  // profiling
-  bool profiling = false;
-  hipEvent_t ev[ST_COUNT + 1]{};
-  bool ev_valid[ST_COUNT + 1]{};
+  // profiling: ring of event sets, one set per render call (slot = call % kEvSlots)
+  // mode 0 off, 1 every stage, 2 only the dominant kernel (cache shader)
+  int profiling = 0;
+  hipEvent_t ev[kEvSlots][ST_COUNT + 1]{};
+  bool ev_used[kEvSlots]{};
   bool ev_created = false;
-  float stage_ms[ST_COUNT]{};
+  int64_t prof_calls = 0;
+  // hipGraph replay of the launch sequence (graph_mode: 0 off, 1 capture when a call repeats, 2 always)
+  int graph_mode = 1;
+  hipStream_t cap_stream = nullptr;
+  std::vector<GraphEntry> graphs;
+  RenderKey last_key{};
+  bool have_last_key = false;
 };
 
 namespace {
@@ -235,6 +257,14 @@ std::vector<float> pack(const std::vector<Step>& steps, const std::vector<Tile>&
   return out;
 }
 
+void append(std::vector<float>& dst, const std::vector<float>& v) { dst.insert(dst.end(), v.begin(), v.end()); }
+// The kernels pull the stream in whole chunks: pad with zero fragments.
+std::vector<float> pad_stream(std::vector<float> v) {
+  const size_t c = (size_t)rc_weight_chunk_floats();
+  v.resize((v.size() + c - 1) / c * c, 0.0f);
+  return v;
+}
+
 int upload(rc_handle* h, const std::string& key, const std::vector<float>& v) {
   DevBuf& b = h->packs[key];
   if (b.bytes != v.size() * sizeof(float)) {
@@ -294,14 +324,13 @@ int repack(rc_handle* h) {
     if (!missing.empty()) return fail(h, RC_ERR_MISSING_WEIGHT, "missing weight: " + missing);
     std::vector<Step> s;
     steps_natural(s, d0->in, 0); step_bias(s);
-    int rc = upload(h, "d0_" + std::to_string(l), pack(s, {tile_full(d0, 0), tile_full(d0, 1)}));
-    if (rc) return rc;
+    std::vector<float> stream = pack(s, {tile_full(d0, 0), tile_full(d0, 1)});
     s.clear(); steps_acc(s, 2, 0); step_bias(s);
-    rc = upload(h, "d1_" + std::to_string(l), pack(s, {tile_full(d1, 0), tile_full(d1, 1)}));
-    if (rc) return rc;
+    append(stream, pack(s, {tile_full(d1, 0), tile_full(d1, 1)}));
     std::vector<Col> regs = {Col{dout, 0}};
     if (dn) { regs.push_back(Col{dn, 0}); regs.push_back(Col{dn, 1}); regs.push_back(Col{dn, 2}); }
-    rc = upload(h, "do_" + std::to_string(l), pack(s, {tile_by_reg(regs)}));
+    append(stream, pack(s, {tile_by_reg(regs)}));
+    int rc = upload(h, "dens_" + std::to_string(l), pad_stream(stream));
     if (rc) return rc;
   }
   const std::string sh = "params/Cache/Shader";
@@ -320,41 +349,36 @@ int repack(rc_handle* h) {
   const HostLayer* lb = need(h, sl + "/layer_bottleneck", missing);
   const HostLayer* la = need(h, sl + "/output_ambient_rgb_layer", missing);
   if (!missing.empty()) return fail(h, RC_ERR_MISSING_WEIGHT, "missing weight: " + missing);
-  int rc;
   {
-    // heads: feature = [density feature (acc order) | appearance (natural)] + bias
+    std::vector<float> stream;
     std::vector<Step> s;
+    // heads: feature = [density feature (acc order) | appearance (natural)] + bias
     steps_acc(s, 2, 0); steps_natural(s, 32, 64); step_bias(s);
     std::vector<Col> regs = {Col{rough, 0}, Col{tint, 0}, Col{tint, 1}, Col{tint, 2}, Col{amb, 0},
                              Col{amb, 1},   Col{amb, 2},  Col{irr, 0},  Col{irr, 1},  Col{irr, 2}};
-    rc = upload(h, "heads", pack(s, {tile_full(bott, 0), tile_full(bott, 1), tile_full(bott, 2), tile_full(bott, 3),
-                                     tile_by_reg(regs)}));
-    if (rc) return rc;
-  }
-  {
-    std::vector<Step> s;
-    steps_acc(s, 4, 0); s.push_back({{128, -2}});         // (n.v | bias)
-    if ((rc = upload(h, "i0", pack(s, {tile_full(i0, 0), tile_full(i0, 1)})))) return rc;
-    s.clear(); steps_acc(s, 2, 0); step_bias(s);
-    if ((rc = upload(h, "i1", pack(s, {tile_full(i1, 0), tile_full(i1, 1)})))) return rc;
-    if ((rc = upload(h, "io", pack(s, {tile_by_reg({Col{io, 0}})})))) return rc;
-  }
-  {
-    std::vector<Step> s;
-    steps_acc(s, 4, 0);
-    for (int i = 0; i < 36; ++i) s.push_back({{128 + i, 128 + 36 + i}});   // IDE (real | imag)
-    step_bias(s);
-    rc = upload(h, "s0", pack(s, {tile_full(l0, 0), tile_full(l0, 1), tile_full(l0, 2), tile_full(l0, 3),
-                                  tile_full(lb, 0, 128), tile_full(lb, 1, 128), tile_full(lb, 2, 128),
-                                  tile_full(lb, 3, 128)}));
-    if (rc) return rc;
-    s.clear(); steps_acc(s, 4, 0); step_bias(s);
-    if ((rc = upload(h, "s1", pack(s, {tile_full(l1, 0), tile_full(l1, 1), tile_full(l1, 2), tile_full(l1, 3)})))) return rc;
-    if ((rc = upload(h, "s2", pack(s, {tile_full(l2, 0), tile_full(l2, 1), tile_full(l2, 2), tile_full(l2, 3)})))) return rc;
-    if ((rc = upload(h, "so", pack(s, {tile_by_reg({Col{la, 0}, Col{la, 1}, Col{la, 2}})})))) return rc;
+    append(stream, pack(s, {tile_full(bott, 0), tile_full(bott, 1), tile_full(bott, 2), tile_full(bott, 3),
+                            tile_by_reg(regs)}));
+    // s0: SLF layer_0 + input part of layer_bottleneck over [bottleneck | IDE (real | imag) | bias]
     s.clear(); steps_acc(s, 4, 0);
-    rc = upload(h, "sb", pack(s, {tile_full(lb, 0, 0, false), tile_full(lb, 1, 0, false), tile_full(lb, 2, 0, false),
-                                  tile_full(lb, 3, 0, false)}));
+    for (int i = 0; i < 36; ++i) s.push_back({{128 + i, 128 + 36 + i}});
+    step_bias(s);
+    append(stream, pack(s, {tile_full(l0, 0), tile_full(l0, 1), tile_full(l0, 2), tile_full(l0, 3),
+                            tile_full(lb, 0, 128), tile_full(lb, 1, 128), tile_full(lb, 2, 128), tile_full(lb, 3, 128)}));
+    // integrated BRDF
+    s.clear(); steps_acc(s, 4, 0); s.push_back({{128, -2}});         // (n.v | bias)
+    append(stream, pack(s, {tile_full(i0, 0), tile_full(i0, 1)}));
+    s.clear(); steps_acc(s, 2, 0); step_bias(s);
+    append(stream, pack(s, {tile_full(i1, 0), tile_full(i1, 1)}));
+    append(stream, pack(s, {tile_by_reg({Col{io, 0}})}));
+    // SLF trunk
+    s.clear(); steps_acc(s, 4, 0); step_bias(s);
+    append(stream, pack(s, {tile_full(l1, 0), tile_full(l1, 1), tile_full(l1, 2), tile_full(l1, 3)}));
+    append(stream, pack(s, {tile_full(l2, 0), tile_full(l2, 1), tile_full(l2, 2), tile_full(l2, 3)}));
+    std::vector<Step> sb; steps_acc(sb, 4, 0);
+    append(stream, pack(sb, {tile_full(lb, 0, 0, false), tile_full(lb, 1, 0, false), tile_full(lb, 2, 0, false),
+                             tile_full(lb, 3, 0, false)}));
+    append(stream, pack(s, {tile_by_reg({Col{la, 0}, Col{la, 1}, Col{la, 2}})}));
+    int rc = upload(h, "shader", pad_stream(stream));
     if (rc) return rc;
   }
   if (!h->ide_table.p) {
@@ -416,6 +440,7 @@ int ensure_workspace(rc_handle* h, int64_t n) {
   if ((rc = ws_alloc(h, "normals_pred", 3 * np))) return rc;
   if ((rc = ws_alloc(h, "app", 32 * np))) return rc;
   if ((rc = ws_alloc(h, "shade", RC_SHADE_CH * np))) return rc;
+  if ((rc = ws_alloc(h, "debug", 20 * ((np + 31) / 32) + 64))) return rc;
   if ((rc = ws_alloc(h, "inds", n))) return rc;
   if ((rc = ws_alloc(h, "src_idx", n))) return rc;
   if ((rc = ws_alloc(h, "filt_weight", n))) return rc;
@@ -423,14 +448,19 @@ int ensure_workspace(rc_handle* h, int64_t n) {
   return RC_OK;
 }
 
-void stage_mark(rc_handle* h, int idx, hipStream_t s) {
-  if (!h->profiling) return;
-  if (!h->ev_created) {
-    for (int i = 0; i <= ST_COUNT; ++i) (void)hipEventCreate(&h->ev[i]);
-    h->ev_created = true;
+void stage_mark(rc_handle* h, int slot, int idx, hipStream_t s) {
+  if (slot < 0) return;
+  if (h->profiling == 2 && idx != ST_SHADER && idx != ST_SHADER + 1) return;
+  (void)hipEventRecord(h->ev[slot][idx], s);
+}
+
+void drop_graphs(rc_handle* h) {
+  for (auto& g : h->graphs) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
   }
-  (void)hipEventRecord(h->ev[idx], s);
-  h->ev_valid[idx] = true;
+  h->graphs.clear();
+  h->have_last_key = false;
 }
 
 __global__ void k_make_src(const int32_t* inds, int32_t* src, int64_t n, int S) {
@@ -503,7 +533,11 @@ void rc_destroy(rc_handle* h) {
   for (auto& kv : h->packs) if (kv.second.p) (void)hipFree(kv.second.p);
   for (auto& kv : h->ws) if (kv.second.p) (void)hipFree(kv.second.p);
   if (h->ide_table.p) (void)hipFree(h->ide_table.p);
-  if (h->ev_created) for (int i = 0; i <= ST_COUNT; ++i) (void)hipEventDestroy(h->ev[i]);
+  drop_graphs(h);
+  if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  if (h->ev_created)
+    for (int s = 0; s < kEvSlots; ++s)
+      for (int i = 0; i <= ST_COUNT; ++i) (void)hipEventDestroy(h->ev[s][i]);
   delete h;
 }
 
@@ -566,12 +600,30 @@ int rc_load_weights(rc_handle* h, const rc_tensor_desc* descs, int32_t n) {
     (leaf == "kernel" ? L.have_kernel : L.have_bias) = true;
     h->packed_dirty = true;
   }
+  drop_graphs(h);   // table pointers / packed fragments are baked into captured kernel arguments
   return RC_OK;
 }
 
 int rc_set_profiling(rc_handle* h, int32_t enabled) {
   if (!h) return RC_ERR_INVALID_ARG;
-  h->profiling = enabled != 0;
+  RC_HIP(h, hipSetDevice(h->device));
+  if (enabled && !h->ev_created) {
+    for (int s = 0; s < kEvSlots; ++s)
+      for (int i = 0; i <= ST_COUNT; ++i) RC_HIP(h, hipEventCreate(&h->ev[s][i]));
+    h->ev_created = true;
+  }
+  if (enabled < 0 || enabled > 2) return fail(h, RC_ERR_INVALID_ARG, "rc_set_profiling: mode must be 0, 1 or 2");
+  h->profiling = enabled;
+  h->prof_calls = 0;
+  for (int s = 0; s < kEvSlots; ++s) h->ev_used[s] = false;
+  return RC_OK;
+}
+
+int rc_set_graph_mode(rc_handle* h, int32_t mode) {
+  if (!h) return RC_ERR_INVALID_ARG;
+  if (mode < 0 || mode > 2) return fail(h, RC_ERR_INVALID_ARG, "rc_set_graph_mode: mode must be 0, 1 or 2");
+  h->graph_mode = mode;
+  if (mode == 0) drop_graphs(h);
   return RC_OK;
 }
 
@@ -579,13 +631,21 @@ int rc_stage_times_ms(rc_handle* h, float* out_ms, int32_t n) {
   if (!h || !out_ms) return RC_ERR_INVALID_ARG;
   if (!h->ev_created) return fail(h, RC_ERR_INVALID_ARG, "rc_stage_times_ms: profiling was not enabled");
   RC_HIP(h, hipSetDevice(h->device));
-  RC_HIP(h, hipEventSynchronize(h->ev[ST_COUNT]));
-  for (int i = 0; i < ST_COUNT; ++i) {
-    float ms = 0.0f;
-    if (h->ev_valid[i] && h->ev_valid[i + 1]) RC_HIP(h, hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
-    h->stage_ms[i] = ms;
-    if (i < n) out_ms[i] = ms;
+  // mean over the event sets recorded since profiling was (re)enabled (at most the last kEvSlots calls)
+  double sum[ST_COUNT] = {0};
+  int used = 0;
+  for (int s = 0; s < kEvSlots; ++s) {
+    if (!h->ev_used[s]) continue;
+    RC_HIP(h, hipEventSynchronize(h->ev[s][h->profiling == 1 ? ST_COUNT : ST_SHADER + 1]));
+    for (int i = 0; i < ST_COUNT; ++i) {
+      float ms = 0.0f;
+      if (h->profiling == 1 || i == ST_SHADER) RC_HIP(h, hipEventElapsedTime(&ms, h->ev[s][i], h->ev[s][i + 1]));
+      sum[i] += ms;
+    }
+    ++used;
   }
+  if (!used) return fail(h, RC_ERR_INVALID_ARG, "rc_stage_times_ms: no profiled render call yet");
+  for (int i = 0; i < ST_COUNT && i < n; ++i) out_ms[i] = (float)(sum[i] / used);
   return RC_OK;
 }
 
@@ -626,31 +686,22 @@ int rc_sample_intervals(rc_handle* h, const float* t, const float* logits, int64
   return RC_OK;
 }
 
-int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_randoms* rnd, uint32_t pass_mask,
-                   const rc_outputs* out, void* stream_v) {
-  if (!h) return RC_ERR_INVALID_ARG;
-  if (!rays || !out) return fail(h, RC_ERR_INVALID_ARG, "rc_render_rays: null rays/outputs");
-  if (n < 0) return fail(h, RC_ERR_INVALID_ARG, "rc_render_rays: negative n_rays");
-  if (n == 0) return RC_OK;
-  if (!rays->origins || !rays->directions || !rays->viewdirs || !rays->near || !rays->far)
-    return fail(h, RC_ERR_INVALID_ARG, "rc_render_rays: origins/directions/viewdirs/near/far are required");
-  if (!(pass_mask & RC_PASS_CACHE)) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_rays: pass_mask must include RC_PASS_CACHE");
-  const bool secondary = (pass_mask & RC_PASS_SECONDARY) != 0;
-  const bool resample = secondary || (pass_mask & RC_PASS_RESAMPLE);
-  if (resample && h->cfg.num_resample != 1) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_rays: num_resample must be 1");
-  if (resample && !(rnd && (rnd->gumbel || rnd->resample_inds)))
-    return fail(h, RC_ERR_INVALID_ARG, "rc_render_rays: resampling needs rc_randoms.gumbel or .resample_inds");
-  if (secondary) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_rays: secondary pass is not available in this build");
-  RC_HIP(h, hipSetDevice(h->device));
-  hipStream_t st = (hipStream_t)stream_v;
-  int rc;
-  if (h->packed_dirty && (rc = repack(h))) return rc;
-  if ((rc = ensure_workspace(h, n))) return rc;
-  rc_shader_prepare();
+namespace {
+
+struct RenderArgs {
+  rc_rays rays; rc_randoms rnd; bool have_rnd; int64_t n; uint32_t mask; rc_outputs out; int slot;
+};
+
+// Enqueue the whole launch sequence on `st` (also used under stream capture).
+void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
   const rc_config& c = h->cfg;
   const int NL = c.num_levels;
-
-  for (int i = 0; i <= ST_COUNT; ++i) h->ev_valid[i] = false;
+  const int64_t n = A.n;
+  const rc_rays* rays = &A.rays;
+  const rc_randoms* rnd = A.have_rnd ? &A.rnd : nullptr;
+  const bool secondary = (A.mask & RC_PASS_SECONDARY) != 0;
+  const bool resample = secondary || (A.mask & RC_PASS_RESAMPLE);
+  const int slot = A.slot;
   for (int l = 0; l < NL; ++l) {
     const std::string L = std::to_string(l), Lp = std::to_string(l - 1);
     const int S = c.num_samples[l];
@@ -672,29 +723,29 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_random
     sa.secondary = secondary ? 1 : 0;
     sa.raydist_p = c.raydist_p; sa.raydist_premult = c.raydist_premult;
     sa.eps_dot_min = c.shadow_normal_eps_dot_min; sa.far_clamp = c.env_map_distance;
-    stage_mark(h, ST_SAMPLE0 + 3 * l, st);
+    stage_mark(h, slot, ST_SAMPLE0 + 3 * l, st);
     rc_launch_sample(sa, st);
 
-    stage_mark(h, ST_GRID0 + 3 * l, st);
+    stage_mark(h, slot, ST_GRID0 + 3 * l, st);
     rc_launch_hashgrid(h->grids[l].dev, W(h, "means" + L), 1, np, W(h, "feat" + L), 1, np, c.contract_radius, nullptr, st);
 
     RcDensityMlpArgs da{};
     da.feat = W(h, "feat" + L); da.n = np; da.ld = np;
     da.K = h->grids[l].dev.num_levels * h->grids[l].dev.num_features;
-    da.w0 = h->packs["d0_" + L].p; da.w1 = h->packs["d1_" + L].p; da.wo = h->packs["do_" + L].p;
+    da.wstream = h->packs["dens_" + L].p;
     da.means = W(h, "means" + L);
     da.density_bias = c.density_bias; da.contract_radius = c.contract_radius; da.bbox = h->grids[l].cfg.bbox;
     da.last = (l == NL - 1) ? 1 : 0;
     da.density = W(h, "density" + L);
     da.hbuf = da.last ? W(h, "hbuf") : nullptr;
     da.normals_pred = da.last ? W(h, "normals_pred") : nullptr;
-    stage_mark(h, ST_MLP0 + 3 * l, st);
+    stage_mark(h, slot, ST_MLP0 + 3 * l, st);
     rc_launch_density_mlp(da, st);
   }
   const std::string LL = std::to_string(NL - 1);
   const int S2 = c.num_samples[NL - 1];
   const int64_t np2 = n * S2;
-  stage_mark(h, ST_RESAMPLE, st);
+  stage_mark(h, slot, ST_RESAMPLE, st);
   const int32_t* src = nullptr;
   if (resample) {
     RcResampleArgs ra{};
@@ -707,23 +758,22 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_random
     src = (const int32_t*)W(h, "src_idx");
   }
   const int64_t nsh = resample ? n : np2;
-  stage_mark(h, ST_GRID_APP, st);
+  stage_mark(h, slot, ST_GRID_APP, st);
   rc_launch_hashgrid_src(h->grids[3].dev, W(h, "means" + LL), 1, src, np2, nsh, W(h, "app"), 1, nsh,
                          c.contract_radius, nullptr, st);
-  stage_mark(h, ST_SHADER, st);
+  stage_mark(h, slot, ST_SHADER, st);
   {
     RcShaderArgs s{};
     s.n = nsh; s.n_src = np2; s.src = src; s.samples_per_ray = resample ? 1 : S2;
     s.hbuf = W(h, "hbuf"); s.app = W(h, "app"); s.normals_pred = W(h, "normals_pred"); s.viewdirs = rays->viewdirs;
-    s.w_heads = h->packs["heads"].p; s.w_i0 = h->packs["i0"].p; s.w_i1 = h->packs["i1"].p; s.w_io = h->packs["io"].p;
-    s.w_s0 = h->packs["s0"].p; s.w_s1 = h->packs["s1"].p; s.w_s2 = h->packs["s2"].p; s.w_sb = h->packs["sb"].p;
-    s.w_so = h->packs["so"].p; s.ide_coef = h->ide_table.p;
+    s.wstream = h->packs["shader"].p; s.ide_coef = h->ide_table.p;
     s.roughness_bias = c.roughness_bias; s.irradiance_bias = c.irradiance_bias; s.ambient_bias = c.ambient_irradiance_bias;
     s.rgb_max = c.rgb_max; s.slf_ambient_bias = c.slf_ambient_bias;
     s.shade = W(h, "shade");
+    s.debug = W(h, "debug");
     rc_launch_shader(s, st);
   }
-  stage_mark(h, ST_COMPOSITE, st);
+  stage_mark(h, slot, ST_COMPOSITE, st);
   {
     RcCompositeArgs ca{};
     ca.directions = rays->directions; ca.origins = rays->origins; ca.lights = rays->lights; ca.n_rays = n; ca.S = S2;
@@ -735,11 +785,98 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_random
     ca.weights = W(h, "weights" + LL);
     ca.bg = secondary ? 0.0f : c.bg_intensity;
     ca.pct[0] = c.percentiles[0]; ca.pct[1] = c.percentiles[1]; ca.pct[2] = c.percentiles[2];
-    ca.out = *out;
+    ca.out = A.out;
     rc_launch_composite(ca, st);
   }
-  stage_mark(h, ST_COUNT, st);
-  RC_HIP(h, hipGetLastError());
+  stage_mark(h, slot, ST_COUNT, st);
+}
+
+}  // namespace
+
+int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_randoms* rnd, uint32_t pass_mask,
+                   const rc_outputs* out, void* stream_v) {
+  if (!h) return RC_ERR_INVALID_ARG;
+  if (!rays || !out) return fail(h, RC_ERR_INVALID_ARG, "rc_render_rays: null rays/outputs");
+  if (n < 0) return fail(h, RC_ERR_INVALID_ARG, "rc_render_rays: negative n_rays");
+  if (n == 0) return RC_OK;
+  if (!rays->origins || !rays->directions || !rays->viewdirs || !rays->near || !rays->far)
+    return fail(h, RC_ERR_INVALID_ARG, "rc_render_rays: origins/directions/viewdirs/near/far are required");
+  if (!(pass_mask & RC_PASS_CACHE)) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_rays: pass_mask must include RC_PASS_CACHE");
+  const bool secondary = (pass_mask & RC_PASS_SECONDARY) != 0;
+  const bool resample = secondary || (pass_mask & RC_PASS_RESAMPLE);
+  if (resample && h->cfg.num_resample != 1) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_rays: num_resample must be 1");
+  if (resample && !(rnd && (rnd->gumbel || rnd->resample_inds)))
+    return fail(h, RC_ERR_INVALID_ARG, "rc_render_rays: resampling needs rc_randoms.gumbel or .resample_inds");
+  if (secondary) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_rays: secondary pass is not available in this build");
+  RC_HIP(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream_v;
+  int rc;
+  if (h->packed_dirty) {
+    drop_graphs(h);
+    if ((rc = repack(h))) return rc;
+  }
+  if (n > h->ws_rays) drop_graphs(h);
+  if ((rc = ensure_workspace(h, n))) return rc;
+  rc_shader_prepare();
+
+  RenderArgs A{};
+  A.rays = *rays;
+  A.have_rnd = rnd != nullptr;
+  if (rnd) A.rnd = *rnd;
+  A.n = n; A.mask = pass_mask; A.out = *out;
+  A.slot = -1;
+  if (h->profiling) {
+    A.slot = (int)(h->prof_calls++ % kEvSlots);
+    h->ev_used[A.slot] = true;
+  }
+
+  if (h->graph_mode == 0 || h->profiling) {   // event records are not replayable graph nodes: profile eagerly
+    enqueue_all(h, A, st);
+    RC_HIP(h, hipGetLastError());
+    return RC_OK;
+  }
+  RenderKey key;
+  memset(&key, 0, sizeof(key));
+  key.n = n; key.mask = pass_mask; key.slot = A.slot;
+  const void* rp[7] = {rays->origins, rays->directions, rays->viewdirs, rays->near, rays->far, rays->lights, rays->normals};
+  memcpy(key.rays, rp, sizeof(rp));
+  if (rnd) {
+    for (int l = 0; l < RC_MAX_LEVELS; ++l) key.rnd[l] = rnd->jitter[l];
+    key.rnd[RC_MAX_LEVELS] = rnd->gumbel; key.rnd[RC_MAX_LEVELS + 1] = rnd->resample_inds;
+  }
+  for (int i = 0; i < RC_OUT_COUNT; ++i) key.out[i] = out->ptr[i];
+  for (auto& g : h->graphs)
+    if (g.key == key) {
+      RC_HIP(h, hipGraphLaunch(g.exec, st));
+      return RC_OK;
+    }
+  const bool capture = h->graph_mode == 2 || (h->have_last_key && h->last_key == key);
+  h->last_key = key;
+  h->have_last_key = true;
+  if (!capture) {
+    enqueue_all(h, A, st);
+    RC_HIP(h, hipGetLastError());
+    return RC_OK;
+  }
+  // capture on a private stream (the caller's may be the legacy default stream), replay on the caller's
+  if (!h->cap_stream) RC_HIP(h, hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+  if (h->graphs.size() >= 64) drop_graphs(h);
+  GraphEntry e;
+  e.key = key;
+  RC_HIP(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+  enqueue_all(h, A, h->cap_stream);
+  hipError_t ce = hipStreamEndCapture(h->cap_stream, &e.graph);
+  if (ce != hipSuccess || !e.graph) {
+    // capture unsupported for this sequence: fall back to eager launches for good
+    (void)hipGetLastError();
+    h->graph_mode = 0;
+    enqueue_all(h, A, st);
+    RC_HIP(h, hipGetLastError());
+    return RC_OK;
+  }
+  RC_HIP(h, hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+  h->graphs.push_back(e);
+  RC_HIP(h, hipGraphLaunch(e.exec, st));
   return RC_OK;
 }
 

@@ -112,7 +112,7 @@ struct RcDensityMlpArgs {
   const float* feat;          // feature-major [K][ld]
   int64_t n; int64_t ld;
   int32_t K;                  // 6, 7 or 32
-  const float* w0; const float* w1; const float* wo;   // packed MFMA fragments
+  const float* wstream;       // packed MFMA fragment stream [d0 | d1 | out]
   const float* means;         // SoA [3][n] (validity mask)
   float density_bias, contract_radius, bbox;
   int32_t last;               // 1: also write hidden feature + predicted normals
@@ -131,11 +131,11 @@ struct RcShaderArgs {
   const float* app;           // appearance features, feature-major [32][n] (already gathered per shaded point)
   const float* normals_pred;  // SoA [3][n_src]
   const float* viewdirs;      // [n_rays,3]
-  const float* w_heads; const float* w_i0; const float* w_i1; const float* w_io;
-  const float* w_s0; const float* w_s1; const float* w_s2; const float* w_sb; const float* w_so;
+  const float* wstream;       // packed MFMA fragment stream [heads | s0 | i0 | i1 | io | s1 | s2 | sb | so]
   const float* ide_coef;      // IDE polynomial table (device)
   float roughness_bias, irradiance_bias, ambient_bias, rgb_max, slf_ambient_bias;
   float* shade;               // SoA [RC_SHADE_CH][n]
+  void* debug;                // diagnostic builds (-DRC_STAMPS): per-tile cycle stamps
 };
 void rc_launch_shader(const RcShaderArgs& a, hipStream_t stream);
 

@@ -34,38 +34,97 @@ __device__ __forceinline__ f32x16 zero16() {
   return z;
 }
 
-// One pass over KS k-steps for NT output tiles.  wp: packed fragments [KS][NT][64]; act: this
-// lane's activation column (act[s * 64] is step s).  Double-buffered in groups of D steps.
-template <int NT, int KS, int D>
-__device__ __forceinline__ void mlp_layer(const float* __restrict__ wp, const float* act, int lane,
-                                          f32x16 (&acc)[NT]) {
-  float a0[D][NT], a1[D][NT], b0[D], b1[D];
-  auto load = [&](float(&a)[D][NT], float(&b)[D], int s0) {
+// ---------------------------------------------------------------------------------------------
+// Weight stream.  All MLP layers of a kernel are packed by the host into ONE linear stream of
+// 256-byte MFMA A-fragments in exactly the order the kernel consumes them.  The workgroup pulls
+// the stream through a two-chunk LDS ring with LDS-DMA (global_load_lds_dwordx4, no VGPRs): while
+// the waves run the MFMAs of chunk c out of LDS, chunk c+1 is in flight.  One barrier per chunk
+// (kChunk fragments = kChunk MFMAs per wave) is the only synchronisation; every wave of the
+// workgroup executes the identical, fully unrolled fragment sequence.
+// ---------------------------------------------------------------------------------------------
+constexpr int kChunk = 64;                       // fragments per chunk (16 KiB)
+constexpr int kRingFloats = 2 * kChunk * 64;     // two chunks
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+struct WStream {
+  const float* g;    // packed fragment stream (padded to a whole number of chunks)
+  float* ring;       // LDS ring [2 * kChunk][64]
+  int lane, wave;
+};
+
+// Issue the LDS-DMA of chunk c (this wave's quarter: 4 x 1 KiB).
+template <int NF>
+__device__ __forceinline__ void ws_issue(const WStream& w, int c) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const int s = s0 + d;
+  for (int k = 0; k < kChunk / 4 / kWaves; ++k) {
+    const int i = w.wave + kWaves * k;             // 1-KiB piece inside the chunk
+    const int frag0 = c * kChunk + 4 * i;
+    if (frag0 < NF) {
+      const float* src = w.g + (size_t)frag0 * 64 + w.lane * 4;
+      float* dst = w.ring + ((c & 1) * kChunk + 4 * i) * 64;
+      __builtin_amdgcn_global_load_lds((const void*)src, (lds_void_ptr)dst, 16, 0, 0);
+    }
+  }
+}
+
+template <int NF>
+__device__ __forceinline__ void ws_begin(const WStream& w) {
+  ws_issue<NF>(w, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (kChunk < NF) ws_issue<NF>(w, 1);
+}
+
+// Entering chunk c: it has landed (issued one chunk ago), everybody is done with chunk c-1.
+template <int NF>
+__device__ __forceinline__ void ws_advance(const WStream& w, int c) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if ((c + 1) * kChunk < NF) ws_issue<NF>(w, c + 1);
+}
+
+// One pass over KS k-steps for NT output tiles; the layer's fragments are [FBASE, FBASE + KS*NT)
+// of the stream.  act: this lane's activation column (act[s * 64] is step s).
+// Software pipelined in groups of SG k-steps: the LDS reads (A fragments + B activations) of group
+// g+1 are issued before the MFMAs of group g, with scheduling fences so they stay there; the MFMA
+// pipe then runs back to back while the next operands are in flight.
+template <int NT, int KS, int FBASE, int NF, int SG = (NT >= 8 ? 1 : (NT >= 4 ? 2 : (NT >= 2 ? 4 : 8)))>
+__device__ __forceinline__ void mlp_layer(const WStream& w, const float* act, f32x16 (&acc)[NT]) {
+  constexpr int NG = (KS + SG - 1) / SG;
+  float a[2][SG][NT], b[2][SG];
+  auto load = [&](int g, int buf) {
+#pragma unroll
+    for (int d = 0; d < SG; ++d) {
+      const int s = g * SG + d;
       if (s < KS) {
-        b[d] = act[s * 64];
+        b[buf][d] = act[s * 64];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) a[d][t] = wp[(s * NT + t) * 64 + lane];
+        for (int t = 0; t < NT; ++t) {
+          const int f = FBASE + s * NT + t;            // compile-time after unrolling
+          if (f > 0 && f % kChunk == 0) ws_advance<NF>(w, f / kChunk);
+          a[buf][d][t] = w.ring[(f % (2 * kChunk)) * 64 + w.lane];
+        }
       }
     }
   };
-  auto comp = [&](float(&a)[D][NT], float(&b)[D], int s0) {
+  auto comp = [&](int g, int buf) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      if (s0 + d < KS) {
+    for (int d = 0; d < SG; ++d) {
+      if (g * SG + d < KS) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][t], b[d], acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][d][t], b[buf][d], acc[t], 0, 0, 0);
       }
     }
   };
-  load(a0, b0, 0);
-  for (int s0 = 0; s0 < KS; s0 += 2 * D) {
-    load(a1, b1, s0 + D);
-    comp(a0, b0, s0);
-    load(a0, b0, s0 + 2 * D);
-    comp(a1, b1, s0 + D);
+  load(0, 0);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) load(g + 1, (g + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    comp(g, g & 1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -115,15 +174,18 @@ constexpr int kDensActSteps = 33;
 
 template <int KS0>   // k-steps of layer 0 including the bias step
 __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a) {
+  __shared__ __attribute__((aligned(16))) float ring[kRingFloats];
   __shared__ float lds[kWaves][kDensActSteps * 64];
+  constexpr int F_D0 = 0, F_D1 = 2 * KS0, F_DO = 2 * KS0 + 66, NF = 2 * KS0 + 99;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
   const int64_t p0 = tile * 32;
-  if (p0 >= a.n) return;
   const int j = lane & 31, h = lane >> 5;
   const int64_t p = p0 + j;
-  const bool valid = p < a.n;
+  const bool valid = p < a.n;        // waves past the end stay alive for the workgroup barriers
   float* act = &lds[wave][lane];
+  WStream ws{a.wstream, ring, lane, wave};
+  ws_begin<NF>(ws);
 
   // stage the grid features (natural k pairs) + bias step
 #pragma unroll
@@ -135,14 +197,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
 
   f32x16 acc[2];
   acc[0] = zero16(); acc[1] = zero16();
-  mlp_layer<2, KS0, 4>(a.w0, act, lane, acc);
+  mlp_layer<2, KS0, F_D0, NF>(ws, act, acc);
   park<2, true>(acc, act, 0);
   act[32 * 64] = h == 0 ? 1.0f : 0.0f;
 
   acc[0] = zero16(); acc[1] = zero16();
-  mlp_layer<2, 33, 4>(a.w1, act, lane, acc);
+  mlp_layer<2, 33, F_D1, NF>(ws, act, acc);
   park<2, true>(acc, act, 0);
-  if (a.last && a.hbuf) {
+  if (a.last && a.hbuf && p0 < a.n) {
     // hidden feature handed to the shader in accumulator (= B operand) layout
     float* hb = a.hbuf + tile * (32 * 64) + lane;
 #pragma unroll
@@ -153,7 +215,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
 
   f32x16 out[1];
   out[0] = zero16();
-  mlp_layer<1, 33, 8>(a.wo, act, lane, out);
+  mlp_layer<1, 33, F_DO, NF>(ws, act, out);
 
   if (h == 0 && valid) {
     // convert_raw_density (geometry.py:318-341)
@@ -171,7 +233,6 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
   }
 }
 
-
 // (l, m) of IDE term i for deg_view = 5: l in {1,2,4,8,16}, m = 0..l (ref_utils.py:105-115)
 __host__ __device__ constexpr int ide_l(int i) { return i < 2 ? 1 : (i < 5 ? 2 : (i < 10 ? 4 : (i < 19 ? 8 : 16))); }
 __host__ __device__ constexpr int ide_m(int i) { return i < 2 ? i : (i < 5 ? i - 2 : (i < 10 ? i - 5 : (i < 19 ? i - 10 : i - 19))); }
@@ -180,23 +241,38 @@ __host__ __device__ constexpr int ide_m(int i) { return i < 2 ? i : (i < 5 ? i -
 // Cache shader
 // ---------------------------------------------------------------------------------------------
 // activation slice (steps): [0,64) bottleneck | [64,100) IDE | 100 bias(1|0) | 101 (dot|1)
+#ifdef RC_STAMPS
+#define RC_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamps[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define RC_STAMP(i) do { } while (0)
+#endif
 constexpr int kShActSteps = 102;
 constexpr int kStepBias = 100;
 constexpr int kStepDot = 101;
 
 __global__ __launch_bounds__(kWaves * 64) void k_cache_shader(RcShaderArgs a) {
-  extern __shared__ float lds_dyn[];
+  extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  // fragment offsets of the layers inside the kernel's weight stream (host: rc_api.hip, same order)
+  constexpr int F_H = 0, F_S0 = F_H + 49 * 5, F_I0 = F_S0 + 101 * 8, F_I1 = F_I0 + 65 * 2, F_IO = F_I1 + 33 * 2,
+                F_S1 = F_IO + 33, F_S2 = F_S1 + 65 * 4, F_SB = F_S2 + 65 * 4, F_SO = F_SB + 64 * 4, NF = F_SO + 65;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
   const int64_t p0 = tile * 32;
-  if (p0 >= a.n) return;
   const int j = lane & 31, h = lane >> 5;
   const int64_t p = p0 + j;
-  const bool valid = p < a.n;
+  const bool valid = p < a.n;        // waves past the end stay alive for the workgroup barriers
   const int64_t pc = valid ? p : a.n - 1;
   const int64_t q = a.src ? (int64_t)a.src[pc] : pc;       // source point of the last level
   const int64_t ray = pc / a.samples_per_ray;
-  float* act = lds_dyn + wave * (kShActSteps * 64) + lane;
+  float* ring = lds_dyn;
+  float* act = lds_dyn + kRingFloats + wave * (kShActSteps * 64) + lane;
+  WStream ws{a.wstream, ring, lane, wave};
+#ifdef RC_STAMPS
+  unsigned long long stamps[12];
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  RC_STAMP(0);
+  ws_begin<NF>(ws);
 
   // ---- stage feature = [density feature (64, accumulator order) | appearance grid (32)] + bias
   {
@@ -207,13 +283,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_shader(RcShaderArgs a) {
     for (int s = 0; s < 16; ++s) act[(32 + s) * 64] = a.app[(int64_t)(2 * s + h) * a.n + pc];
     act[48 * 64] = h == 0 ? 1.0f : 0.0f;
   }
+  RC_STAMP(1);
   // ---- heads: bottleneck (4 tiles, linear) + small heads tile
   float rough, tint[3], ad[3], idf[3];
   {
     f32x16 acc[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t) acc[t] = zero16();
-    mlp_layer<5, 49, 2>(a.w_heads, act, lane, acc);
+    mlp_layer<5, 49, F_H, NF>(ws, act, acc);
     // heads tile, by accumulator register (same on both half-waves): 0 roughness, 1-3 tint,
     // 4-6 ambient irradiance, 7-9 irradiance
     rough = softplus(acc[4][0] + a.roughness_bias);                       // nerf.py:633-634
@@ -228,6 +305,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_shader(RcShaderArgs a) {
     f32x16 bt[4] = {acc[0], acc[1], acc[2], acc[3]};
     park<4, false>(bt, act, 0);
   }
+  RC_STAMP(2);
   // ---- normals, n.(-v), reflection direction, IDE
   {
     const float nx = a.normals_pred[q], ny = a.normals_pred[a.n_src + q], nz = a.normals_pred[2 * a.n_src + q];
@@ -270,28 +348,31 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_shader(RcShaderArgs a) {
   }
   // ---- SLF layer_0 (tiles 0-3) + input part of layer_bottleneck (tiles 4-7): one pass over
   //      [bottleneck | IDE | bias]; results stay in registers while the IBRDF chain runs.
+  RC_STAMP(3);
   f32x16 s0[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) s0[t] = zero16();
-  mlp_layer<8, 101, 1>(a.w_s0, act, lane, s0);
+  mlp_layer<8, 101, F_S0, NF>(ws, act, s0);
+  RC_STAMP(4);
   // ---- integrated BRDF: (bottleneck, n.v) 129 -> 64 -> 64 -> 1 (nerf.py:461-482)
   float ibrdf;
   {
     f32x16 ib[2];
     ib[0] = zero16(); ib[1] = zero16();
-    mlp_layer<2, 64, 4>(a.w_i0, act, lane, ib);
-    mlp_layer<2, 1, 1>(a.w_i0 + 64 * 2 * 64, act + kStepDot * 64, lane, ib);   // (n.v | bias) step
+    mlp_layer<2, 64, F_I0, NF>(ws, act, ib);
+    mlp_layer<2, 1, F_I0 + 128, NF>(ws, act + kStepDot * 64, ib);   // (n.v | bias) step
     // IDE is dead now: steps [64, 97) are scratch for the IBRDF tail
     park<2, true>(ib, act, 64);
     act[(64 + 32) * 64] = h == 0 ? 1.0f : 0.0f;
     ib[0] = zero16(); ib[1] = zero16();
-    mlp_layer<2, 33, 4>(a.w_i1, act + 64 * 64, lane, ib);
+    mlp_layer<2, 33, F_I1, NF>(ws, act + 64 * 64, ib);
     park<2, true>(ib, act, 64);
     f32x16 o[1];
     o[0] = zero16();
-    mlp_layer<1, 33, 8>(a.w_io, act + 64 * 64, lane, o);
+    mlp_layer<1, 33, F_IO, NF>(ws, act + 64 * 64, o);
     ibrdf = sigmoidf(o[0][0] + 1.0986123f);     // + log(3), nerf.py:481
   }
+  RC_STAMP(5);
   // ---- SLF trunk: layer_1, layer_2, layer_bottleneck (x part accumulates onto the input part)
   float amb[3];
   {
@@ -301,20 +382,29 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_shader(RcShaderArgs a) {
     act[64 * 64] = h == 0 ? 1.0f : 0.0f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = zero16();
-    mlp_layer<4, 65, 2>(a.w_s1, act, lane, acc);
+    mlp_layer<4, 65, F_S1, NF>(ws, act, acc);
     park<4, true>(acc, act, 0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = zero16();
-    mlp_layer<4, 65, 2>(a.w_s2, act, lane, acc);
+    mlp_layer<4, 65, F_S2, NF>(ws, act, acc);
     park<4, true>(acc, act, 0);
-    mlp_layer<4, 64, 2>(a.w_sb, act, lane, skip);
+    mlp_layer<4, 64, F_SB, NF>(ws, act, skip);
     park<4, true>(skip, act, 0);
     f32x16 o[1];
     o[0] = zero16();
-    mlp_layer<1, 65, 8>(a.w_so, act, lane, o);
+    mlp_layer<1, 65, F_SO, NF>(ws, act, o);
 #pragma unroll
     for (int c = 0; c < 3; ++c) amb[c] = fmaxf(softplus(o[0][c] + a.slf_ambient_bias), 0.0f);   // slf.py:1053-1059
   }
+  RC_STAMP(6);
+#ifdef RC_STAMPS
+  if (lane == 0 && a.debug) {
+    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(a.debug) + tile * 10;
+    for (int i = 0; i < 7; ++i) d[i] = stamps[i];
+    d[7] = rt0; d[8] = rt1;
+  }
+#endif
   // ---- combine (nerf.py:1034-1053); ambient_specular is an exact 0 (ref_acc == 1)
   if (h == 0 && valid) {
 #pragma unroll
@@ -346,7 +436,8 @@ void rc_launch_density_mlp(const RcDensityMlpArgs& a, hipStream_t stream) {
   }
 }
 
-int rc_shader_lds_bytes() { return kWaves * kShActSteps * 64 * (int)sizeof(float); }
+int rc_shader_lds_bytes() { return (kRingFloats + kWaves * kShActSteps * 64) * (int)sizeof(float); }
+int rc_weight_chunk_floats() { return kChunk * 64; }
 
 // The shader's per-wave activation slices exceed the default 64 KiB dynamic-LDS limit.
 void rc_shader_prepare() {

@@ -1,0 +1,294 @@
+"""Python host layer: the reference's call signatures on top of the C ABI.
+
+Mirrors, for the radiance-cache hot path only:
+  * model.apply(variables, rng, rays, **render_kwargs) -> {"render": {...}, ...}
+      BaseMaterialModel.__call__              internal/models.py:1144-1254
+  * create_render_fn(model) -> render_fn(rng, rays, passes, resample)
+      train_utils.create_render_fn            internal/train_utils.py:3742-3831
+  * render_image(render_fn, rng, rays, config, passes, ...) -> (rendering, rng)
+      models.render_image                     internal/models.py:2361-2525
+  * utils.shard / utils.unshard               internal/utils.py:333-343
+
+One process drives one GPU (torch.distributed rank); `n_local_devices` is therefore 1 and the
+leading device axis of the reference's pmap outputs is kept with size 1 so callers that index
+`v[0]` keep working.  Ray batches are sharded across ranks at image granularity by
+`render_image_distributed`, with one all-gather of the consumed keys per image (RCCL over xGMI
+via torch.distributed's "nccl" backend; "gloo" on CPU for the tests).
+
+Randomness: jax.random (threefry) is not reproduced.  `rng` may be
+  * None                         -> the reference's rng=None deterministic branch,
+  * a numpy Generator / int seed -> per-level ray jitter (and Gumbel noise) drawn here,
+  * a dict {"jitter": [...], "gumbel": ..., "resample_inds": ...} of explicit tensors.
+"""
+from __future__ import annotations
+
+import time
+from typing import Any, Dict, Optional, Tuple
+
+import numpy as np
+
+from . import rc_ext
+from .config import RenderConfig
+from .rays import Rays
+
+# keys of _finalize_outputs (internal/models.py:2087-2111) that get a `cache_` alias
+_FINAL_INTEGRATOR_KEYS = (
+    "rgb", "normals", "normals_pred", "incoming_rgb", "env_map_rgb", "incoming_s_dist", "diffuse_rgb",
+    "specular_rgb", "occ", "indirect_occ", "direct_rgb", "indirect_rgb", "ambient_rgb", "irradiance_rgb",
+    "light_radiance_rgb", "n_dot_l_rgb", "albedo_rgb", "direct_diffuse_rgb", "direct_specular_rgb",
+    "indirect_diffuse_rgb", "indirect_specular_rgb", "ambient_diffuse_rgb", "ambient_specular_rgb",
+)
+# device outputs the primary cache pass computes
+_CACHE_DEVICE_KEYS = ("rgb", "acc", "distance_mean", "distance_percentile_5", "distance_median",
+                      "distance_percentile_95", "diffuse_rgb", "specular_rgb", "direct_rgb", "indirect_rgb",
+                      "albedo_rgb", "indirect_diffuse_rgb", "indirect_specular_rgb", "indirect_occ", "means",
+                      "normals", "normals_pred", "ray_dists", "light_dists")
+
+
+def flatten_variables(variables: Dict[str, Any], prefix: str = "") -> Dict[str, Any]:
+    """Flax variable tree {"params": {"Cache": {...}}} -> {"params/Cache/...": array}."""
+    flat = {}
+    for k, v in variables.items():
+        name = f"{prefix}/{k}" if prefix else k
+        if isinstance(v, dict):
+            flat.update(flatten_variables(v, name))
+        else:
+            flat[name] = v
+    return flat
+
+
+def _draw_randoms(rng, n: int, cfg: RenderConfig, need_gumbel: bool):
+    if rng is None:
+        return None, None
+    if isinstance(rng, dict):
+        return rng, None
+    if isinstance(rng, (int, np.integer)):
+        rng = np.random.Generator(np.random.PCG64(int(rng)))
+    out = {"jitter": [rng.uniform(size=(n,)).astype(np.float32) for _ in range(cfg.num_levels)]}
+    if need_gumbel:
+        out["gumbel"] = rng.gumbel(size=(n, cfg.sampling_strategy[-1][2])).astype(np.float32)
+    return out, rng
+
+
+class Model:
+    """Cache stage of MaterialModel (use_material=False): `apply` keeps the reference signature."""
+
+    def __init__(self, config: Optional[RenderConfig] = None, device: int = 0):
+        self.config = config or RenderConfig()
+        self.device = device
+        self.rc = rc_ext.RadianceCache(self.config, device)   # raises if librc_hip.so is missing
+        self._variables_id = None
+
+    def load_variables(self, variables: Dict[str, Any]):
+        flat = flatten_variables(variables) if any(isinstance(v, dict) for v in variables.values()) else variables
+        self.rc.load_weights(flat)
+        self._variables_id = id(variables)
+
+    def apply(self, variables, rng, rays: Rays, *, train_frac: float = 1.0, train: bool = False,
+              passes: Tuple[str, ...] = ("cache",), compute_extras: bool = False, is_secondary: bool = False,
+              resample: Any = None, sampling_strategy=None, **unused_render_kwargs):
+        """model.apply(variables, rng, rays, ...) (internal/models.py:1144-1254).
+
+        `variables` may be None once `load_variables` was called (they live on the device).
+        Only the inference branch exists here: train must be False and train_frac 1.0.
+        """
+        if train or train_frac != 1.0:
+            raise NotImplementedError("only the render-time path (train=False, train_frac=1.0) is accelerated")
+        if sampling_strategy is not None and tuple(sampling_strategy) != tuple(self.config.sampling_strategy):
+            raise NotImplementedError("sampling_strategy is fixed when the handle is created")
+        if "material" in passes:
+            raise NotImplementedError("material pass: not part of this build (SURVEY.md §8, config 3)")
+        if variables is not None and id(variables) != self._variables_id:
+            self.load_variables(variables)
+        fields = rays.hot_fields() if isinstance(rays, Rays) else dict(rays)
+        n = int(np.prod(np.shape(fields["near"])))
+        mask = rc_ext.RC_PASS_CACHE
+        if is_secondary or "is_secondary" in passes:
+            mask |= rc_ext.RC_PASS_SECONDARY
+        if resample:
+            mask |= rc_ext.RC_PASS_RESAMPLE
+        need_gumbel = bool(mask & (rc_ext.RC_PASS_SECONDARY | rc_ext.RC_PASS_RESAMPLE))
+        randoms, _ = _draw_randoms(rng, n, self.config, need_gumbel)
+        dev = self.rc.render_rays(fields, randoms, mask, outputs=_CACHE_DEVICE_KEYS)
+        render = self._finalize(dev, fields)
+        return {"render": render, "main": {"integrator": render}, "cache_main": {"integrator": render}}
+
+    __call__ = apply
+
+    def _finalize(self, dev: Dict[str, Any], fields) -> Dict[str, Any]:
+        """Integrator keys + the aliases/constants of _finalize_outputs (internal/models.py:2074-2171)."""
+        import torch
+
+        r = dict(dev)
+        zeros3 = torch.zeros_like(r["rgb"])
+        # exact duplicates / exact zeros of the configured passive shader (internal/nerf.py:1044-1084)
+        r["ambient_rgb"] = r["direct_rgb"]
+        r["direct_diffuse_rgb"] = r["direct_rgb"]
+        r["ambient_diffuse_rgb"] = r["direct_rgb"]
+        for k in ("occ", "irradiance_rgb", "light_radiance_rgb", "n_dot_l_rgb", "direct_specular_rgb",
+                  "ambient_specular_rgb"):
+            r[k] = zeros3
+        r["normals_to_use"] = r["normals_pred"]
+        r["ray_dists"] = r["ray_dists"][:, None]
+        r["light_dists"] = r["light_dists"][:, None]
+        for k in _FINAL_INTEGRATOR_KEYS:
+            if k in r:
+                r["cache_" + k] = r[k]
+        r["vignette"] = torch.ones_like(r["rgb"][:, :1])
+        lossmult = fields.get("lossmult")
+        lm = torch.ones_like(r["rgb"][:, :1]) if lossmult is None else self.rc._dev(lossmult).reshape(-1, 1)
+        r["lossmult"] = lm * torch.ones_like(r["rgb"])
+        return r
+
+
+# ------------------------------------------------------------------------------------------------
+# utils.shard / unshard, create_render_fn, render_image
+# ------------------------------------------------------------------------------------------------
+def shard(xs, n_local_devices: int = 1):
+    """utils.shard (internal/utils.py:333-335) with jax.local_device_count() == 1 per process."""
+    fn = lambda x: x.reshape((n_local_devices, -1) + tuple(x.shape[1:]))
+    return xs.tree_map(fn) if isinstance(xs, Rays) else fn(xs)
+
+
+def unshard(x, padding: int = 0):
+    """utils.unshard (internal/utils.py:338-343)."""
+    y = x.reshape((x.shape[0] * x.shape[1],) + tuple(x.shape[2:]))
+    return y[:-padding] if padding > 0 else y
+
+
+def create_render_fn(model: Model, variables=None):
+    """render_fn(rng, sharded_rays, passes, resample) -> (renderings, rng); values carry the
+    [n_dev=1, n_dev=1, m, ...] leading axes of the reference's pmap + all_gather
+    (internal/train_utils.py:3795-3830) so `unshard(v[0], padding)` applies unchanged."""
+
+    def render_fn(rng, rays: Rays, passes, resample=None):
+        flat = rays.tree_map(lambda x: x.reshape((-1,) + tuple(x.shape[2:])))
+        out = model.apply(variables, rng, flat, train=False, passes=passes, resample=resample, compute_extras=True)
+        render = {k: v[None, None] for k, v in out["render"].items()}
+        return render, rng
+
+    return render_fn
+
+
+def render_image(render_fn, rng, rays: Rays, config, passes: Tuple[str, ...], verbose: bool = True,
+                 resample: Any = None, num_repeats: int = 1, compute_variance: bool = False):
+    """models.render_image (internal/models.py:2361-2525): chunked host loop, edge padding,
+    Welford mean over repeats, row-major scatter into [H, W, ...] float32 numpy arrays."""
+    height, width = rays.origins.shape[:2]
+    num_rays = height * width
+    rays = rays.tree_map(lambda r: np.asarray(r).reshape((num_rays, -1)) if np.size(r) >= num_rays else np.asarray(r))
+    stat_keys = ["rgb", "integrated_rgb", "lighting_irradiance", "direct_rgb", "indirect_rgb", "material_rgb",
+                 "specular_rgb", "diffuse_rgb", "material_albedo", "acc"]
+    var_keys = ["rgb", "integrated_rgb"]
+    transient_keys = ["transient_direct_viz", "transient_indirect_viz"]
+    rendering = None
+    chunk = config.render_chunk_size
+    idx0s = range(0, num_rays, chunk)
+    start = time.time()
+    for i_chunk, idx0 in enumerate(idx0s):
+        if verbose and i_chunk % max(1, len(idx0s) // 10) == 0:
+            print(f"Rendering chunk {i_chunk}/{len(idx0s)-1}")
+        chunk_size = min(chunk, num_rays - idx0)
+        chunk_rays = rays.tree_map(lambda r: r[idx0: idx0 + chunk_size])
+        padding = 0
+        if chunk_size % chunk != 0:
+            padding = chunk - (chunk_size % chunk)
+            chunk_rays = chunk_rays.tree_map(lambda r: np.pad(r, ((0, padding), (0, 0)), mode="edge"))
+        chunk_rays = shard(chunk_rays)
+        means: Dict[str, np.ndarray] = {}
+        m2: Dict[str, np.ndarray] = {}
+        for i_repeat in range(num_repeats):
+            cur, rng = render_fn(rng, chunk_rays, passes, resample)
+            cur = {k: np.array(unshard(v[0].cpu().numpy() if hasattr(v, "cpu") else np.asarray(v[0]), padding))
+                   for k, v in cur.items()}
+            if rendering is None:
+                rendering = {}
+                for k, v in cur.items():
+                    if ("transient" in k) and (k not in transient_keys):
+                        continue
+                    rendering[k] = np.zeros((height, width) + v.shape[1:], dtype=v.dtype)
+                    if compute_variance and k in var_keys:
+                        rendering[f"{k}_variance"] = np.zeros_like(rendering[k])
+            for k, v in cur.items():
+                if ("transient" in k) and (k not in transient_keys):
+                    continue
+                if k not in means:
+                    means[k] = v.copy()
+                    if compute_variance and num_repeats > 1 and k in var_keys:
+                        m2[k] = np.zeros_like(v)
+                elif k in stat_keys:
+                    delta = v - means[k]
+                    means[k] += delta / (i_repeat + 1)
+                    if compute_variance and num_repeats > 1 and k in var_keys:
+                        m2[k] += delta * (v - means[k])
+        ind = np.arange(chunk_size)
+        ys, xs = (idx0 + ind) // width, (idx0 + ind) % width
+        for k, v in means.items():
+            rendering[k][ys, xs] = v[:chunk_size]
+            if compute_variance and num_repeats > 1 and k in var_keys and k in m2:
+                rendering[f"{k}_variance"][ys, xs] = ((m2[k] / (num_repeats - 1)) * num_repeats)[:chunk_size]
+    if verbose:
+        print("Milliseconds per ray", (time.time() - start) * 1000 / (height * width))
+    return rendering, rng
+
+
+# ------------------------------------------------------------------------------------------------
+# Multi-GPU: one process per GPU, rays sharded at image granularity, one all-gather per image
+# ------------------------------------------------------------------------------------------------
+GATHER_KEYS = ("rgb", "acc", "distance_median", "normals_pred")
+
+
+def shard_bounds(num_rays: int, rank: int, world: int) -> Tuple[int, int]:
+    """Static contiguous split: rank r owns rays [r*ceil(N/G), ...)."""
+    per = -(-num_rays // world)
+    lo = min(rank * per, num_rays)
+    return lo, min(lo + per, num_rays)
+
+
+def render_image_distributed(model_apply, rng, rays: Rays, config, passes=("cache",), keys=GATHER_KEYS,
+                             group=None, device=None, key_widths: Optional[Dict[str, int]] = None):
+    """Each rank renders its contiguous share of the image in `render_chunk_size` batches, keeps the
+    results on its device, packs the consumed keys into one [rays_per_rank, sum(widths)] buffer and
+    issues ONE all_gather per image (the reference all-gathers the whole ~45-key dict per chunk per
+    repeat, internal/train_utils.py:3795-3815).
+
+    model_apply(rng, rays) -> {"render": {key: tensor[n, ...]}}; runs on "nccl" (= RCCL over xGMI)
+    with the HIP model and on "gloo" with any CPU callable (tests)."""
+    import torch
+    import torch.distributed as dist
+
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    widths = dict(rc_ext.OUTPUTS)
+    if key_widths:
+        widths.update(key_widths)
+    cols = np.cumsum([0] + [widths[k] for k in keys])
+    height, width = rays.origins.shape[:2]
+    num_rays = height * width
+    flat = rays.tree_map(lambda r: np.asarray(r).reshape((num_rays, -1)) if np.size(r) >= num_rays else np.asarray(r))
+    lo, hi = shard_bounds(num_rays, rank, world)
+    per = -(-num_rays // world)
+    chunk = config.render_chunk_size
+    buf = None
+    for idx0 in range(lo, hi, chunk):
+        sub = flat.tree_map(lambda r: r[idx0: min(idx0 + chunk, hi)])
+        out = model_apply(rng, sub)["render"]
+        if buf is None:
+            dev = device or out[keys[0]].device
+            buf = torch.zeros((per, int(cols[-1])), dtype=torch.float32, device=dev)
+        m = min(idx0 + chunk, hi) - idx0
+        for i, k in enumerate(keys):
+            buf[idx0 - lo: idx0 - lo + m, cols[i]: cols[i + 1]] = out[k].reshape(m, -1)
+    if buf is None:
+        buf = torch.zeros((per, int(cols[-1])), dtype=torch.float32, device=device or "cpu")
+    if world > 1:
+        gathered = torch.empty((world * per, int(cols[-1])), dtype=torch.float32, device=buf.device)
+        dist.all_gather(list(gathered.chunk(world, dim=0)), buf, group=group)
+    else:
+        gathered = buf
+    result = {}
+    for i, k in enumerate(keys):
+        v = gathered[:num_rays, cols[i]: cols[i + 1]]
+        result[k] = v.reshape((height, width) + ((widths[k],) if widths[k] > 1 else ()))
+    return result

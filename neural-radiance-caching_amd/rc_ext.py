@@ -73,7 +73,7 @@ class rc_outputs(C.Structure):
 EXPORTS = (
     "rc_create", "rc_destroy", "rc_last_error", "rc_abi_version", "rc_load_weights", "rc_render_rays",
     "rc_hashgrid_lookup", "rc_sample_intervals", "rc_workspace_ptr", "rc_set_profiling", "rc_stage_count",
-    "rc_stage_name", "rc_stage_times_ms",
+    "rc_stage_name", "rc_stage_times_ms", "rc_set_graph_mode",
 )
 
 _LIB = None
@@ -115,6 +115,8 @@ def load_library():
     lib.rc_workspace_ptr.restype = C.c_int
     lib.rc_set_profiling.argtypes = [C.c_void_p, C.c_int32]
     lib.rc_set_profiling.restype = C.c_int
+    lib.rc_set_graph_mode.argtypes = [C.c_void_p, C.c_int32]
+    lib.rc_set_graph_mode.restype = C.c_int
     lib.rc_stage_count.restype = C.c_int
     lib.rc_stage_name.argtypes = [C.c_int32]
     lib.rc_stage_name.restype = C.c_char_p
@@ -222,9 +224,11 @@ class RadianceCache:
         return x.to(device=f"cuda:{self.device}", dtype=dtype).contiguous()
 
     def render_rays(self, rays: Dict[str, object], randoms: Optional[Dict[str, object]] = None,
-                    pass_mask: int = RC_PASS_CACHE, outputs: Optional[Iterable[str]] = None):
+                    pass_mask: int = RC_PASS_CACHE, outputs: Optional[Iterable[str]] = None,
+                    out: Optional[Dict[str, object]] = None):
         """rays: dict with origins, directions, viewdirs [n,3], near, far [n] or [n,1], optional lights,
-        normals.  Returns dict name -> torch cuda tensor ([n,3] or [n])."""
+        normals.  Returns dict name -> torch cuda tensor ([n,3] or [n]).  Passing the dict returned by
+        an earlier call as `out` reuses its buffers (same pointers -> the captured hipGraph is replayed)."""
         torch = self._torch
         r = rc_rays()
         held = {}
@@ -258,16 +262,21 @@ class RadianceCache:
                 rnd.resample_inds = held["inds"].data_ptr()
             rnd_p = C.byref(rnd)
         names = [nm for nm, _ in OUTPUTS] if outputs is None else list(outputs)
-        out = rc_outputs()
+        if out is not None:
+            names = list(out.keys())
+        cout = rc_outputs()
         res = {}
         dev = f"cuda:{self.device}"
         for nm in names:
             width = OUTPUTS[OUTPUT_ID[nm]][1]
-            t = torch.zeros((n, 3) if width == 3 else (n,), dtype=torch.float32, device=dev)
+            shape = (n, 3) if width == 3 else (n,)
+            t = out[nm] if out is not None else torch.zeros(shape, dtype=torch.float32, device=dev)
+            if tuple(t.shape) != shape or not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError(f"output buffer {nm}: expected contiguous float32 cuda tensor of shape {shape}")
             res[nm] = t
-            out.ptr[OUTPUT_ID[nm]] = t.data_ptr()
+            cout.ptr[OUTPUT_ID[nm]] = t.data_ptr()
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        self._check(self.lib.rc_render_rays(self._h, C.byref(r), n, rnd_p, pass_mask, C.byref(out), stream))
+        self._check(self.lib.rc_render_rays(self._h, C.byref(r), n, rnd_p, pass_mask, C.byref(cout), stream))
         self._keep = [held]   # keep inputs alive until the next call (async enqueue)
         return res
 
@@ -307,8 +316,12 @@ class RadianceCache:
         _memcpy_d2h(host.ctypes.data, ptr.value, cnt.value * 4)
         return host.view(np.int32) if dtype == np.int32 else host
 
-    def set_profiling(self, enabled: bool):
+    def set_profiling(self, enabled):
         self._check(self.lib.rc_set_profiling(self._h, int(enabled)))
+
+    def set_graph_mode(self, mode: int):
+        """0 eager launches, 1 capture a hipGraph when a call repeats (default), 2 capture at once."""
+        self._check(self.lib.rc_set_graph_mode(self._h, int(mode)))
 
     def stage_times_ms(self) -> Dict[str, float]:
         n = self.lib.rc_stage_count()

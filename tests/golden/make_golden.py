@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz with the CPU oracle in float64 ("spec" precision).
+
+The reference (JAX/Flax/gin) cannot be imported or run in the build image and ships no
+fixtures for this path, so these vectors are produced by the oracle itself:
+they pin the oracle against regressions and give the HIP path a float64 target, they do NOT
+pin the oracle to the reference (parity unpinned, see oracle/__init__.py).
+
+Inputs are regenerated from seeds (nrc_amd.synthetic_rays / synthetic_weights), only outputs
+are stored (float32-rounded float64 results).
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import nrc_amd  # noqa: E402
+import common  # noqa: E402
+from oracle import cache_ref, hashgrid_ref, mathx, stepfun_ref  # noqa: E402
+
+F64 = torch.float64
+
+
+def cache_case(n_rays, jitter_seed, density_shift, name):
+    out = common.oracle_cache(n_rays, dtype=F64, jitter_seed=jitter_seed, density_shift=density_shift)
+    d = {}
+    for l, lvl in enumerate(out["sampler"]):
+        for k in ("sdist", "tdist", "density", "weights"):
+            d[f"l{l}_{k}"] = lvl[k].numpy().astype(np.float32)
+    d["shade_rgb"] = out["shader"]["rgb"].numpy().astype(np.float32)
+    for k, v in out["render"].items():
+        d["render_" + k] = v.numpy().astype(np.float32)
+    d["meta"] = np.array([n_rays, -1 if jitter_seed is None else jitter_seed, density_shift], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, name), **d)
+    print(name, {k: v.shape for k, v in list(d.items())[:4]}, "...")
+
+
+def operator_cases():
+    cfg = nrc_amd.hotdog_config()
+    wt = common.weights_torch(dtype=F64)
+    rng = np.random.default_rng(123)
+    pts = rng.uniform(-3, 3, size=(512, 3)).astype(np.float32)
+    pts[:8] = [[0, 0, 0], [1, 1, 1], [-1, -1, -1], [2, 0, 0], [0, -2, 0], [0.999, 0.999, 0.999], [5, 5, 5], [-5, 3, 0.1]]
+    d = {"points": pts}
+    grids = [("params/Cache/Sampler/MLP_0/density_grid", cfg.proposal_grids[0]),
+             ("params/Cache/Sampler/MLP_1/density_grid", cfg.proposal_grids[1]),
+             ("params/Cache/Sampler/MLP_2/density_grid", cfg.proposal_grids[2]),
+             ("params/Cache/Shader/appearance_grid", cfg.appearance_grid)]
+    for gid, (prefix, g) in enumerate(grids):
+        x = mathx.contract_radius(torch.from_numpy(pts).to(F64), cfg.contract_radius)
+        d[f"grid{gid}"] = hashgrid_ref.hash_encoding(wt, prefix, g, x).numpy().astype(np.float32)
+    # sample_intervals: random histogram, spiky histogram, single bin
+    P, S, n = 64, 32, 64
+    t = np.sort(rng.uniform(size=(n, P + 1)), axis=-1).astype(np.float32)
+    t[:, 0], t[:, -1] = 0, 1
+    lg = (rng.normal(size=(n, P)) * 3).astype(np.float32)
+    lg[:8] = -30.0
+    lg[np.arange(8), rng.integers(0, P, 8)] = 10.0        # spiky
+    jit = rng.uniform(size=(n, 1)).astype(np.float32)
+    d.update(si_t=t, si_logits=lg, si_jitter=jit)
+    d["si_out_det"] = stepfun_ref.sample_intervals(None, torch.from_numpy(t).to(F64), torch.from_numpy(lg).to(F64), S).numpy().astype(np.float32)
+    d["si_out_jit"] = stepfun_ref.sample_intervals(torch.from_numpy(jit).to(F64), torch.from_numpy(t).to(F64), torch.from_numpy(lg).to(F64), S).numpy().astype(np.float32)
+    t1 = np.tile(np.array([[0.0, 1.0]], dtype=np.float32), (4, 1))
+    d["si_out_1bin"] = stepfun_ref.sample_intervals(None, torch.from_numpy(t1).to(F64), torch.zeros(4, 1, dtype=F64), 64).numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "operators.npz"), **d)
+    print("operators.npz", list(d.keys()))
+
+
+if __name__ == "__main__":
+    cache_case(256, None, 0.0, "hotdog_cache_256_det.npz")
+    cache_case(256, 7, 0.0, "hotdog_cache_256_jit.npz")
+    cache_case(64, 11, 4.0, "hotdog_cache_64_shell.npz")
+    operator_cases()

@@ -1,0 +1,287 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Tolerances (BASELINE.json north_star): RGB L-inf <= 1e-4 in fp32.  Geometry extras that are sums of
+O(1) positions/distances get 5e-4; raw hash-grid features of points far outside the scene (where the
+contraction amplifies one-ulp coordinate differences by N = 2048) get 2e-3.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import common
+import nrc_amd
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RGB_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def rc():
+    from nrc_amd import rc_ext
+    h = rc_ext.RadianceCache(nrc_amd.hotdog_config(), 0)
+    h.load_weights(common.weights_np())
+    return h
+
+
+@pytest.fixture(scope="module")
+def rc_shell():
+    from nrc_amd import rc_ext
+    h = rc_ext.RadianceCache(nrc_amd.hotdog_config(), 0)
+    h.load_weights(common.weights_np(4.0))
+    return h
+
+
+def _render(rc, n, jitter_seed=None, seed=20200823, **kw):
+    rays = nrc_amd.synthetic_rays(n, seed=seed)
+    rnd = None if jitter_seed is None else {"jitter": common.jitters(n, seed=jitter_seed)}
+    out = rc.render_rays(rays.hot_fields(), rnd, **kw)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+# ---------------------------------------------------------------------------------------------
+# single operators
+# ---------------------------------------------------------------------------------------------
+def test_hashgrid_operator_vs_oracle_and_golden(rc):
+    from oracle import hashgrid_ref, mathx
+    g = dict(np.load(os.path.join(GOLD, "operators.npz")))
+    cfg = nrc_amd.hotdog_config()
+    wt = common.weights_torch()
+    grids = [("params/Cache/Sampler/MLP_0/density_grid", cfg.proposal_grids[0]),
+             ("params/Cache/Sampler/MLP_1/density_grid", cfg.proposal_grids[1]),
+             ("params/Cache/Sampler/MLP_2/density_grid", cfg.proposal_grids[2]),
+             ("params/Cache/Shader/appearance_grid", cfg.appearance_grid)]
+    pts = g["points"]
+    for gid, (prefix, gc) in enumerate(grids):
+        out = rc.hashgrid_lookup(gid, pts).cpu().numpy()
+        ref = hashgrid_ref.hash_encoding(wt, prefix, gc, mathx.contract_radius(torch.from_numpy(pts), 2.0)).numpy()
+        assert out.shape == ref.shape == (pts.shape[0], gc.out_dim)
+        assert np.abs(out - ref).max() <= 2e-3
+        assert np.abs(out - g[f"grid{gid}"]).max() <= 2e-3
+
+
+def test_hashgrid_inside_unit_ball_is_bit_exact(rc):
+    """Where the contraction is the identity every step is exactly rounded fp32 -> bitwise equal."""
+    from oracle import hashgrid_ref, mathx
+    cfg = nrc_amd.hotdog_config()
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-1.1, 1.1, size=(4096, 3)).astype(np.float32)      # |x/2| < 1
+    wt = common.weights_torch()
+    out = rc.hashgrid_lookup(2, pts).cpu().numpy()
+    ref = hashgrid_ref.hash_encoding(wt, "params/Cache/Sampler/MLP_2/density_grid", cfg.proposal_grids[2],
+                                     mathx.contract_radius(torch.from_numpy(pts), 2.0)).numpy()
+    assert np.array_equal(out, ref)
+
+
+def test_hashgrid_without_contraction_negative_and_outside_coords(rc):
+    from oracle import hashgrid_ref
+    cfg = nrc_amd.hotdog_config()
+    pts = np.array([[-1.7, 0.3, 1.9], [-0.999, -0.999, -0.999], [1.0, 1.0, 1.0], [0.0, 0.0, 0.0],
+                    [-1.0, 0.5, 0.25], [1.499, -1.499, 0.001]], dtype=np.float32)
+    out = rc.hashgrid_lookup(3, pts, apply_contraction=False).cpu().numpy()
+    ref = hashgrid_ref.hash_encoding(common.weights_torch(), "params/Cache/Shader/appearance_grid",
+                                     cfg.appearance_grid, torch.from_numpy(pts)).numpy()
+    assert np.array_equal(out, ref)
+    # dense levels (first 3 x F) of a point outside the bbox are exactly zero (zero padding)
+    assert np.all(out[0, :12] == 0.0) and np.any(out[0, 12:] != 0.0)
+
+
+def test_hashgrid_empty_and_single_point(rc):
+    assert rc.hashgrid_lookup(0, np.zeros((0, 3), np.float32)).shape == (0, 6)
+    assert rc.hashgrid_lookup(1, np.zeros((1, 3), np.float32)).shape == (1, 7)
+
+
+def test_sample_intervals_operator(rc):
+    from oracle import stepfun_ref
+    g = dict(np.load(os.path.join(GOLD, "operators.npz")))
+    t, lg, jit = g["si_t"], g["si_logits"], g["si_jitter"]
+    out = rc.sample_intervals(t, lg, 32).cpu().numpy()
+    ref = stepfun_ref.sample_intervals(None, torch.from_numpy(t), torch.from_numpy(lg), 32).numpy()
+    assert np.abs(out - ref).max() <= 2e-5 and np.abs(out - g["si_out_det"]).max() <= 1e-4
+    out = rc.sample_intervals(t, lg, 32, jit).cpu().numpy()
+    assert np.abs(out - g["si_out_jit"]).max() <= 1e-4
+    assert np.all(np.diff(out, axis=-1) >= 0) and out.min() >= 0 and out.max() <= 1
+    # single bin -> 64 samples (level 0 of the sampler)
+    t1 = np.tile(np.array([[0.0, 1.0]], np.float32), (4, 1))
+    out = rc.sample_intervals(t1, np.zeros((4, 1), np.float32), 64).cpu().numpy()
+    assert np.abs(out - g["si_out_1bin"]).max() <= 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# the hot path
+# ---------------------------------------------------------------------------------------------
+CHECK_3 = ("diffuse_rgb", "specular_rgb", "direct_rgb", "indirect_rgb", "albedo_rgb", "indirect_diffuse_rgb",
+           "indirect_specular_rgb", "indirect_occ")
+
+
+@pytest.mark.parametrize("jitter_seed", [None, 7])
+def test_cache_render_256_vs_oracle_fp32(rc, jitter_seed):
+    n = 256
+    out = _render(rc, n, jitter_seed)
+    ref = common.oracle_cache(n, jitter_seed=jitter_seed, want_grad_normals=False)
+    r = {k: v.numpy() for k, v in ref["render"].items()}
+    assert np.abs(out["rgb"] - r["rgb"]).max() <= RGB_TOL
+    assert np.abs(out["acc"] - r["acc"]).max() <= RGB_TOL
+    for k in CHECK_3:
+        assert np.abs(out[k] - r[k]).max() <= RGB_TOL, k
+    for k in ("means", "normals_pred"):
+        assert np.abs(out[k] - r[k]).max() <= 5e-4, k
+    for k in ("ray_dists", "light_dists"):
+        assert np.abs(out[k] - r[k][:, 0]).max() <= 5e-4, k
+    for k in ("distance_mean", "distance_median", "distance_percentile_5", "distance_percentile_95"):
+        assert np.abs(out[k] - r[k]).max() <= 1e-3, k
+    # intermediate stages
+    for l, S in enumerate((64, 64, 32)):
+        assert np.abs(rc.workspace(f"sdist{l}").reshape(n, S + 1) - ref["sampler"][l]["sdist"].numpy()).max() <= 2e-5
+        assert np.abs(rc.workspace(f"tdist{l}").reshape(n, S + 1) - ref["sampler"][l]["tdist"].numpy()).max() <= 1e-4
+        assert np.abs(rc.workspace(f"weights{l}").reshape(n, S) - ref["sampler"][l]["weights"].numpy()).max() <= 2e-4
+    # level 0 sits on bit-identical sample positions -> the density MLP is compared tightly
+    d0 = rc.workspace("density0").reshape(n, 64)
+    assert np.abs(d0 - ref["sampler"][0]["density"].numpy()).max() <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["hotdog_cache_256_det.npz", "hotdog_cache_256_jit.npz"])
+def test_cache_render_vs_fp64_golden(rc, name):
+    g = dict(np.load(os.path.join(GOLD, name)))
+    n, js = int(g["meta"][0]), int(g["meta"][1])
+    out = _render(rc, n, None if js < 0 else js)
+    assert np.abs(out["rgb"] - g["render_rgb"]).max() <= RGB_TOL
+    assert np.abs(out["acc"] - g["render_acc"]).max() <= RGB_TOL
+    for k in CHECK_3:
+        assert np.abs(out[k] - g["render_" + k]).max() <= 2e-4, k
+
+
+def test_cache_render_shell_weights_saturated_rays(rc_shell):
+    """Second weight set (+4 on the density bias): rays saturate, early samples dominate."""
+    g = dict(np.load(os.path.join(GOLD, "hotdog_cache_64_shell.npz")))
+    n, js = int(g["meta"][0]), int(g["meta"][1])
+    out = _render(rc_shell, n, js)
+    assert g["render_acc"].min() > 0.99
+    assert np.abs(out["rgb"] - g["render_rgb"]).max() <= RGB_TOL
+    assert np.abs(out["acc"] - g["render_acc"]).max() <= RGB_TOL
+    ref = common.oracle_cache(n, jitter_seed=js, density_shift=4.0, want_grad_normals=False)["render"]
+    assert np.abs(out["rgb"] - ref["rgb"].numpy()).max() <= RGB_TOL
+    assert np.abs(out["distance_median"] - ref["distance_median"].numpy()).max() <= 1e-3
+
+
+@pytest.mark.parametrize("n", [1, 3, 31, 33, 100, 1000])
+def test_ragged_batch_sizes(rc, n):
+    """n not a multiple of the 4-ray workgroups / 32-point MFMA tiles / 128-point MLP workgroups."""
+    out = _render(rc, n, outputs=["rgb", "acc"])
+    ref = common.oracle_cache(n, want_grad_normals=False)["render"]
+    assert out["rgb"].shape == (n, 3)
+    assert np.abs(out["rgb"] - ref["rgb"].numpy()).max() <= RGB_TOL
+    assert np.abs(out["acc"] - ref["acc"].numpy()).max() <= RGB_TOL
+
+
+def test_empty_batch_is_a_noop(rc):
+    rays = nrc_amd.synthetic_rays(4)
+    f = {k: np.asarray(v)[:0] for k, v in rays.hot_fields().items()}
+    out = rc.render_rays(f, None, outputs=["rgb"])
+    assert out["rgb"].shape == (0, 3)
+
+
+def test_full_size_batch_properties_1024(rc):
+    """BASELINE configs[1] size; size-independent properties instead of an oracle run."""
+    n = 1024
+    out = _render(rc, n, jitter_seed=3)
+    acc, rgb = out["acc"], out["rgb"]
+    assert np.all(np.isfinite(rgb)) and acc.min() >= 0 and acc.max() <= 1 + 1e-6
+    # rgb = direct + indirect + (1 - acc) * bg (bg = 1); diffuse + specular = direct + indirect
+    assert np.abs(rgb - (out["direct_rgb"] + out["indirect_rgb"] + (1 - acc)[:, None])).max() <= 2e-6
+    assert np.abs(out["diffuse_rgb"] + out["specular_rgb"] - out["direct_rgb"] - out["indirect_rgb"]).max() <= 2e-6
+    assert np.abs(out["indirect_occ"] - acc[:, None]).max() <= 2e-6
+    for l, S in enumerate((64, 64, 32)):
+        sd = rc.workspace(f"sdist{l}").reshape(n, S + 1)
+        td = rc.workspace(f"tdist{l}").reshape(n, S + 1)
+        assert np.all(np.diff(sd, axis=-1) >= 0) and sd.min() >= 0 and sd.max() <= 1
+        assert td.min() >= 2.0 - 1e-6 and td.max() <= 6.0 + 1e-6
+    w2 = rc.workspace("weights2").reshape(n, 32)
+    assert np.abs(w2.sum(-1) - acc).max() <= 2e-6
+    assert np.all(out["distance_percentile_5"] <= out["distance_median"] + 1e-6)
+    assert np.all(out["distance_median"] <= out["distance_percentile_95"] + 1e-6)
+    # linearity of the composite in the per-sample colours: sum_s w_s * shade_rgb_s + (1-acc)
+    sh = rc.workspace("shade").reshape(15, n, 32)
+    recon = (w2[None] * sh[0:3]).sum(-1).T + (1 - acc)[:, None]
+    assert np.abs(recon - rgb).max() <= 5e-6
+
+
+def test_determinism_and_graph_replay_equals_eager(rc):
+    rays = nrc_amd.synthetic_rays(512)
+    f = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in rays.hot_fields().items()}
+    rc.set_graph_mode(0)
+    a = rc.render_rays(f, None)
+    torch.cuda.synchronize()
+    a = {k: v.clone() for k, v in a.items()}
+    rc.set_graph_mode(2)
+    buf = rc.render_rays(f, None)             # captures
+    b = rc.render_rays(f, None, out=buf)      # replays
+    torch.cuda.synchronize()
+    rc.set_graph_mode(1)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_errors_are_reported_not_fatal(rc):
+    from nrc_amd import rc_ext
+    rays = nrc_amd.synthetic_rays(8).hot_fields()
+    with pytest.raises(rc_ext.RcError, match="resampling needs"):
+        rc.render_rays(rays, None, pass_mask=rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_RESAMPLE)
+    with pytest.raises(rc_ext.RcError, match="unknown tensor"):
+        rc.load_weights({"params/Nope/kernel": np.zeros((2, 2), np.float32)})
+    with pytest.raises(rc_ext.RcError, match="bad shape"):
+        rc.load_weights({"params/Cache/Shader/tint_layer/kernel": np.zeros((95, 3), np.float32)})
+    h = rc_ext.RadianceCache(nrc_amd.hotdog_config(), 0)
+    with pytest.raises(rc_ext.RcError, match="missing weight"):
+        h.render_rays(rays, None)
+    # the original handle is still usable
+    out = rc.render_rays(rays, None, outputs=["rgb"])
+    assert torch.isfinite(out["rgb"]).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# host layer: Model.apply / render_image keep the reference's signatures and keys
+# ---------------------------------------------------------------------------------------------
+def test_model_apply_render_dict_matches_oracle_keys():
+    from nrc_amd import model as M
+    cfg = nrc_amd.hotdog_config()
+    m = M.Model(cfg, 0)
+    variables = {"params": {}}
+    for k, v in common.weights_np().items():
+        node = variables
+        parts = k.split("/")
+        for p in parts[:-1]:
+            node = node.setdefault(p, {})
+        node[parts[-1]] = v
+    rays = nrc_amd.synthetic_rays(64)
+    out = m.apply(variables, None, rays, train=False, passes=("cache",), compute_extras=True)["render"]
+    ref = common.oracle_cache(64, want_grad_normals=True)["render"]
+    assert set(out.keys()) == set(ref.keys())
+    for k, v in ref.items():
+        got = out[k].cpu().numpy()
+        assert got.shape == tuple(v.shape), k
+        if "normals" in k and "pred" not in k and "to_use" not in k:
+            continue                                   # analytic normals: see test_analytic_normals
+        tol = 1e-3 if ("dist" in k or k.endswith("means")) else RGB_TOL * (5 if "normals" in k else 1)
+        assert np.abs(got - v.numpy()).max() <= tol, k
+
+
+def test_render_image_matches_oracle_on_small_image():
+    from nrc_amd import model as M
+    cfg = nrc_amd.hotdog_config(render_chunk_size=256)
+    m = M.Model(cfg, 0)
+    m.load_variables(common.weights_np())
+    rays = nrc_amd.synthetic_camera_rays(18, 20)        # 360 rays -> chunks of 256 + 104 (padded)
+    img, _ = M.render_image(M.create_render_fn(m), None, rays, cfg, ("cache",), verbose=False)
+    assert img["rgb"].shape == (18, 20, 3) and img["acc"].shape == (18, 20) and img["rgb"].dtype == np.float32
+    from oracle import cache_ref
+    flat = rays.tree_map(lambda r: np.asarray(r).reshape(360, -1))
+    ref = cache_ref.cache_forward(common.weights_torch(), cfg, common.rays_torch(flat), None,
+                                  want_grad_normals=False)["render"]
+    err = np.abs(img["rgb"].reshape(360, 3) - ref["rgb"].numpy()).max()
+    mse = float(np.mean((img["rgb"].reshape(360, 3) - ref["rgb"].numpy()) ** 2))
+    psnr = -10.0 * np.log10(max(mse, 1e-30))
+    assert err <= RGB_TOL and psnr >= 80.0, (err, psnr)
