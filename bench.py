@@ -163,7 +163,10 @@ def main():
                    "launch": "eager" if (args.profile_mode or args.graph_mode == 0) else "hipGraph"},
         "roofline": {"kernel": "k_cache_shader", "bound": "mfma", "achieved": achieved_tf,
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
-                     "traffic": None, "avg_launch_ms": sh_ms,
+                     # HBM-side bytes per launch from the rocprofv3 PMC passes kept under profiles/
+                     # (FETCH_SIZE 8933.5 KiB uncorrected + WRITE_SIZE 1920 KiB); not re-measured here
+                     "traffic": (8933.5 + 1920.0) * 1024, "traffic_source": "profiles/r01_pmc_summary.txt",
+                     "avg_launch_ms": sh_ms,
                      "algorithmic_flop_per_launch": flops},
         "hashgrid": {"kernels": "k_hashgrid_fwd x4 (grid0, grid1, grid2, grid_app)", "bound": "hbm",
                      "achieved": grid_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": grid_gbs / PEAK_HBM_GBS,
