@@ -76,6 +76,7 @@ struct rc_handle {
   GridState grids[6];
   std::map<std::string, HostLayer> layers;   // key: path without /kernel|/bias
   bool packed_dirty = true;
+  bool have_envmap = false;
   // packed MFMA fragments (device)
   std::map<std::string, DevBuf> packs;
   DevBuf ide_table;
@@ -381,6 +382,40 @@ int repack(rc_handle* h) {
     int rc = upload(h, "shader", pad_stream(stream));
     if (rc) return rc;
   }
+  {
+    // model-level EnvMap (secondary-ray background); optional until a secondary pass is requested
+    std::string miss;
+    const std::string ep = "params/Cache/EnvMap";
+    const HostLayer* e0 = need(h, ep + "/layer_0", miss);
+    const HostLayer* e1 = need(h, ep + "/layer_1", miss);
+    const HostLayer* e2 = need(h, ep + "/layer_2", miss);
+    const HostLayer* eb = need(h, ep + "/layer_bottleneck", miss);
+    const HostLayer* eo = need(h, ep + "/output_rgba_layer", miss);
+    h->have_envmap = miss.empty();
+    if (h->have_envmap) {
+      std::vector<float> stream;
+      std::vector<Step> s;
+      auto tiles8 = [&](const HostLayer* L) {
+        std::vector<Tile> t;
+        for (int i = 0; i < 8; ++i) t.push_back(tile_full(L, i));
+        return t;
+      };
+      steps_natural(s, 27, 0); step_bias(s);
+      append(stream, pack(s, tiles8(e0)));
+      s.clear(); steps_acc(s, 8, 0); step_bias(s);
+      append(stream, pack(s, tiles8(e1)));
+      append(stream, pack(s, tiles8(e2)));
+      s.clear(); steps_acc(s, 8, 0);
+      append(stream, pack(s, {tile_full(eb, 0, 0, false), tile_full(eb, 1, 0, false), tile_full(eb, 2, 0, false),
+                              tile_full(eb, 3, 0, false)}));
+      s.clear(); steps_natural(s, 27, 0); step_bias(s);
+      append(stream, pack(s, {tile_full(eb, 0, 256), tile_full(eb, 1, 256), tile_full(eb, 2, 256), tile_full(eb, 3, 256)}));
+      s.clear(); steps_acc(s, 4, 0); step_bias(s);
+      append(stream, pack(s, {tile_by_reg({Col{eo, 0}, Col{eo, 1}, Col{eo, 2}})}));
+      int rc = upload(h, "envmap", pad_stream(stream));
+      if (rc) return rc;
+    }
+  }
   if (!h->ide_table.p) {
     RcIdeTable tb;
     build_ide_table(tb);
@@ -441,6 +476,9 @@ int ensure_workspace(rc_handle* h, int64_t n) {
   if ((rc = ws_alloc(h, "app", 32 * np))) return rc;
   if ((rc = ws_alloc(h, "shade", RC_SHADE_CH * np))) return rc;
   if ((rc = ws_alloc(h, "debug", 20 * ((np + 31) / 32) + 64))) return rc;
+  if ((rc = ws_alloc(h, "env_rgb", 3 * n))) return rc;
+  if ((rc = ws_alloc(h, "rgb_noenv", 3 * n))) return rc;
+  if ((rc = ws_alloc(h, "acc_ws", n))) return rc;
   if ((rc = ws_alloc(h, "inds", n))) return rc;
   if ((rc = ws_alloc(h, "src_idx", n))) return rc;
   if ((rc = ws_alloc(h, "filt_weight", n))) return rc;
@@ -461,6 +499,22 @@ void drop_graphs(rc_handle* h) {
   }
   h->graphs.clear();
   h->have_last_key = false;
+}
+
+// Secondary rays: rgb += env * (1 - acc) (Model._composite_env_map, internal/models.py:423-460).
+__global__ void k_env_combine(int64_t n, const float* rgb_noenv, const float* acc, const float* env, float* rgb_out,
+                              float* acc_out, float* env_out, float* noenv_out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const float a = acc[r];
+  if (acc_out) acc_out[r] = a;
+  for (int c = 0; c < 3; ++c) {
+    const float base = rgb_noenv[3 * r + c];
+    const float e = env ? env[3 * r + c] : 0.0f;
+    if (rgb_out) rgb_out[3 * r + c] = env ? base + e * (1.0f - a) : base;
+    if (env_out) env_out[3 * r + c] = e;
+    if (noenv_out) noenv_out[3 * r + c] = base;
+  }
 }
 
 __global__ void k_make_src(const int32_t* inds, int32_t* src, int64_t n, int S) {
@@ -786,7 +840,24 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     ca.bg = secondary ? 0.0f : c.bg_intensity;
     ca.pct[0] = c.percentiles[0]; ca.pct[1] = c.percentiles[1]; ca.pct[2] = c.percentiles[2];
     ca.out = A.out;
+    if (secondary) {
+      ca.out.ptr[RC_OUT_RGB] = W(h, "rgb_noenv");
+      ca.out.ptr[RC_OUT_ACC] = W(h, "acc_ws");
+    }
     rc_launch_composite(ca, st);
+  }
+  if (secondary) {
+    const bool use_env = !(A.mask & RC_PASS_NO_ENVMAP);
+    if (use_env) {
+      RcEnvMapArgs ea{};
+      ea.n = n; ea.viewdirs = rays->viewdirs; ea.wstream = h->packs["envmap"].p;
+      ea.rgb_bias = c.env_rgb_bias; ea.env_rgb = W(h, "env_rgb");
+      rc_launch_envmap(ea, st);
+    }
+    hipLaunchKernelGGL(k_env_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n,
+                       (const float*)W(h, "rgb_noenv"), (const float*)W(h, "acc_ws"),
+                       use_env ? (const float*)W(h, "env_rgb") : (const float*)nullptr, A.out.ptr[RC_OUT_RGB],
+                       A.out.ptr[RC_OUT_ACC], A.out.ptr[RC_OUT_ENV_MAP_RGB], A.out.ptr[RC_OUT_RGB_NO_ENV]);
   }
   stage_mark(h, slot, ST_COUNT, st);
 }
@@ -807,7 +878,6 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_random
   if (resample && h->cfg.num_resample != 1) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_rays: num_resample must be 1");
   if (resample && !(rnd && (rnd->gumbel || rnd->resample_inds)))
     return fail(h, RC_ERR_INVALID_ARG, "rc_render_rays: resampling needs rc_randoms.gumbel or .resample_inds");
-  if (secondary) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_rays: secondary pass is not available in this build");
   RC_HIP(h, hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream_v;
   int rc;
@@ -815,6 +885,8 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_random
     drop_graphs(h);
     if ((rc = repack(h))) return rc;
   }
+  if (secondary && !(pass_mask & RC_PASS_NO_ENVMAP) && !h->have_envmap)
+    return fail(h, RC_ERR_MISSING_WEIGHT, "missing weight: params/Cache/EnvMap/* (secondary rays composite the model-level EnvMap)");
   if (n > h->ws_rays) drop_graphs(h);
   if ((rc = ensure_workspace(h, n))) return rc;
   rc_shader_prepare();

@@ -141,9 +141,9 @@ void rc_launch_shader(const RcShaderArgs& a, hipStream_t stream);
 
 // Model-level EnvMap MLP on ray directions (secondary-ray background).
 struct RcEnvMapArgs {
-  int64_t n; const float* viewdirs;
-  const float* w0; const float* w1; const float* w2; const float* wb; const float* wo;
-  float rgb_bias; float* env_rgb;  // [n,3]
+  int64_t n; const float* viewdirs;   // [n,3]
+  const float* wstream;               // packed fragments [e0 | e1 | e2 | eb(x) | eb(inputs) | out]
+  float rgb_bias; float* env_rgb;     // [n,3]
 };
 void rc_launch_envmap(const RcEnvMapArgs& a, hipStream_t stream);
 

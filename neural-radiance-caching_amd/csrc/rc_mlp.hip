@@ -54,11 +54,11 @@ struct WStream {
 };
 
 // Issue the LDS-DMA of chunk c (this wave's quarter: 4 x 1 KiB).
-template <int NF>
+template <int NF, int W = kWaves>
 __device__ __forceinline__ void ws_issue(const WStream& w, int c) {
 #pragma unroll
-  for (int k = 0; k < kChunk / 4 / kWaves; ++k) {
-    const int i = w.wave + kWaves * k;             // 1-KiB piece inside the chunk
+  for (int k = 0; k < kChunk / 4 / W; ++k) {
+    const int i = w.wave + W * k;                  // 1-KiB piece inside the chunk
     const int frag0 = c * kChunk + 4 * i;
     if (frag0 < NF) {
       const float* src = w.g + (size_t)frag0 * 64 + w.lane * 4;
@@ -68,20 +68,20 @@ __device__ __forceinline__ void ws_issue(const WStream& w, int c) {
   }
 }
 
-template <int NF>
+template <int NF, int W = kWaves>
 __device__ __forceinline__ void ws_begin(const WStream& w) {
-  ws_issue<NF>(w, 0);
+  ws_issue<NF, W>(w, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (kChunk < NF) ws_issue<NF>(w, 1);
+  if (kChunk < NF) ws_issue<NF, W>(w, 1);
 }
 
 // Entering chunk c: it has landed (issued one chunk ago), everybody is done with chunk c-1.
-template <int NF>
+template <int NF, int W = kWaves>
 __device__ __forceinline__ void ws_advance(const WStream& w, int c) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if ((c + 1) * kChunk < NF) ws_issue<NF>(w, c + 1);
+  if ((c + 1) * kChunk < NF) ws_issue<NF, W>(w, c + 1);
 }
 
 // One pass over KS k-steps for NT output tiles; the layer's fragments are [FBASE, FBASE + KS*NT)
@@ -89,7 +89,7 @@ __device__ __forceinline__ void ws_advance(const WStream& w, int c) {
 // Software pipelined in groups of SG k-steps: the LDS reads (A fragments + B activations) of group
 // g+1 are issued before the MFMAs of group g, with scheduling fences so they stay there; the MFMA
 // pipe then runs back to back while the next operands are in flight.
-template <int NT, int KS, int FBASE, int NF, int SG = (NT >= 8 ? 1 : (NT >= 4 ? 2 : (NT >= 2 ? 4 : 8)))>
+template <int NT, int KS, int FBASE, int NF, int SG = (NT >= 8 ? 1 : (NT >= 4 ? 2 : (NT >= 2 ? 4 : 8))), int W = kWaves>
 __device__ __forceinline__ void mlp_layer(const WStream& w, const float* act, f32x16 (&acc)[NT]) {
   constexpr int NG = (KS + SG - 1) / SG;
   float a[2][SG][NT], b[2][SG];
@@ -102,7 +102,7 @@ __device__ __forceinline__ void mlp_layer(const WStream& w, const float* act, f3
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int f = FBASE + s * NT + t;            // compile-time after unrolling
-          if (f > 0 && f % kChunk == 0) ws_advance<NF>(w, f / kChunk);
+          if (f > 0 && f % kChunk == 0) ws_advance<NF, W>(w, f / kChunk);
           a[buf][d][t] = w.ring[(f % (2 * kChunk)) * 64 + w.lane];
         }
       }
@@ -421,6 +421,80 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_shader(RcShaderArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Model-level EnvMap (background of secondary rays): pos_enc(dir, 0, 4) [27] -> 256 -> 256 -> 256
+// -> concat input (283) -> 128 -> rgba; rgb = clip(softplus(raw + rgb_bias), 0, inf).
+// Replaces Model._handle_env_map -> SurfaceLightFieldMLP.__call__ as configured by
+// NeRFModel.env_map_params (internal/models.py:360-421, internal/surface_light_field.py:480-499,
+// 1011-1058, internal/coord.py:298-312).  One wave = 32 rays; 2 waves per workgroup (the 256-wide
+// activations need 129 LDS steps per wave).
+// ---------------------------------------------------------------------------------------------
+constexpr int kEnvWaves = 2;
+constexpr int kEnvActSteps = 130;
+
+__global__ __launch_bounds__(kEnvWaves * 64) void k_envmap(RcEnvMapArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  constexpr int KS_IN = 15;   // 14 natural pairs of the 27 inputs (+1 zero pad) + bias
+  constexpr int F_E0 = 0, F_E1 = F_E0 + KS_IN * 8, F_E2 = F_E1 + 129 * 8, F_EB = F_E2 + 129 * 8,
+                F_EI = F_EB + 128 * 4, F_EO = F_EI + KS_IN * 4, NF = F_EO + 65;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t tile = (int64_t)blockIdx.x * kEnvWaves + wave;
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t p = tile * 32 + j;
+  const bool valid = p < a.n;
+  const int64_t pc = valid ? p : a.n - 1;
+  float* ring = lds_dyn;
+  float* act = lds_dyn + kRingFloats + wave * (kEnvActSteps * 64) + lane;
+  WStream ws{a.wstream, ring, lane, wave};
+  ws_begin<NF, kEnvWaves>(ws);
+
+  // pos_enc(x, 0, 4, append_identity): [x(3), sin(2^j x)(12), sin(2^j x + pi/2)(12)]
+  const float d[3] = {a.viewdirs[3 * pc], a.viewdirs[3 * pc + 1], a.viewdirs[3 * pc + 2]};
+  auto enc = [&](int k) -> float {
+    if (k < 3) return d[k];
+    if (k >= 27) return 0.0f;
+    const int q = (k - 3) % 12, second = (k - 3) / 12;
+    const float sx = d[q % 3] * (float)(1 << (q / 3));
+    return sinf(second ? sx + 1.5707963267948966f : sx);
+  };
+  auto stage_inputs = [&]() {
+#pragma unroll
+    for (int s = 0; s < KS_IN - 1; ++s) act[s * 64] = enc(2 * s + h);
+    act[(KS_IN - 1) * 64] = h == 0 ? 1.0f : 0.0f;
+  };
+  stage_inputs();
+  f32x16 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = zero16();
+  mlp_layer<8, KS_IN, F_E0, NF, 1, kEnvWaves>(ws, act, acc);
+  park<8, true>(acc, act, 0);
+  act[128 * 64] = h == 0 ? 1.0f : 0.0f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = zero16();
+  mlp_layer<8, 129, F_E1, NF, 1, kEnvWaves>(ws, act, acc);
+  park<8, true>(acc, act, 0);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = zero16();
+  mlp_layer<8, 129, F_E2, NF, 1, kEnvWaves>(ws, act, acc);
+  park<8, true>(acc, act, 0);
+  // layer_bottleneck on concat([x2 (256), inputs (27)]): x part, then the re-staged input part (+bias)
+  f32x16 bt[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) bt[t] = zero16();
+  mlp_layer<4, 128, F_EB, NF, 2, kEnvWaves>(ws, act, bt);
+  stage_inputs();
+  mlp_layer<4, KS_IN, F_EI, NF, 2, kEnvWaves>(ws, act, bt);
+  park<4, true>(bt, act, 0);
+  act[64 * 64] = h == 0 ? 1.0f : 0.0f;
+  f32x16 o[1];
+  o[0] = zero16();
+  mlp_layer<1, 65, F_EO, NF, 8, kEnvWaves>(ws, act, o);
+  if (h == 0 && valid) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.env_rgb[3 * p + c] = fmaxf(softplus(o[0][c] + a.rgb_bias), 0.0f);
+  }
+}
+
 }  // namespace
 
 void rc_launch_density_mlp(const RcDensityMlpArgs& a, hipStream_t stream) {
@@ -453,4 +527,17 @@ void rc_launch_shader(const RcShaderArgs& a, hipStream_t stream) {
   const int64_t tiles = (a.n + 31) / 32;
   dim3 grid((unsigned)((tiles + kWaves - 1) / kWaves)), block(kWaves * 64);
   hipLaunchKernelGGL(k_cache_shader, grid, block, rc_shader_lds_bytes(), stream, a);
+}
+
+void rc_launch_envmap(const RcEnvMapArgs& a, hipStream_t stream) {
+  if (a.n <= 0) return;
+  static bool prepared = false;
+  const int lds = (kRingFloats + kEnvWaves * kEnvActSteps * 64) * (int)sizeof(float);
+  if (!prepared) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_envmap), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    prepared = true;
+  }
+  const int64_t tiles = (a.n + 31) / 32;
+  dim3 grid((unsigned)((tiles + kEnvWaves - 1) / kEnvWaves)), block(kEnvWaves * 64);
+  hipLaunchKernelGGL(k_envmap, grid, block, lds, stream, a);
 }

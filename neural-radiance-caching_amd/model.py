@@ -39,6 +39,7 @@ _FINAL_INTEGRATOR_KEYS = (
     "indirect_diffuse_rgb", "indirect_specular_rgb", "ambient_diffuse_rgb", "ambient_specular_rgb",
 )
 # device outputs the primary cache pass computes
+_SECONDARY_DEVICE_KEYS = ("env_map_rgb", "rgb_no_env")
 _CACHE_DEVICE_KEYS = ("rgb", "acc", "distance_mean", "distance_percentile_5", "distance_median",
                       "distance_percentile_95", "diffuse_rgb", "specular_rgb", "direct_rgb", "indirect_rgb",
                       "albedo_rgb", "indirect_diffuse_rgb", "indirect_specular_rgb", "indirect_occ", "means",
@@ -109,8 +110,18 @@ class Model:
             mask |= rc_ext.RC_PASS_RESAMPLE
         need_gumbel = bool(mask & (rc_ext.RC_PASS_SECONDARY | rc_ext.RC_PASS_RESAMPLE))
         randoms, _ = _draw_randoms(rng, n, self.config, need_gumbel)
-        dev = self.rc.render_rays(fields, randoms, mask, outputs=_CACHE_DEVICE_KEYS)
+        secondary = bool(mask & rc_ext.RC_PASS_SECONDARY)
+        if secondary and unused_render_kwargs.get("use_env_map") is False:
+            mask |= rc_ext.RC_PASS_NO_ENVMAP
+        keys = _CACHE_DEVICE_KEYS + (_SECONDARY_DEVICE_KEYS if secondary else ())
+        dev = self.rc.render_rays(fields, randoms, mask, outputs=keys)
         render = self._finalize(dev, fields)
+        if secondary:
+            # Model._handle_secondary (internal/models.py:309-460): *_no_stopgrad copies, env composite
+            acc1 = render["acc"][:, None]
+            render["rgb_no_stopgrad"] = render["rgb"]
+            render["acc_no_stopgrad"] = render["acc"]
+            render.pop("rgb_no_env")
         return {"render": render, "main": {"integrator": render}, "cache_main": {"integrator": render}}
 
     __call__ = apply

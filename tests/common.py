@@ -32,3 +32,26 @@ def oracle_cache(n_rays, dtype=torch.float32, jitter_seed=None, density_shift=0.
     rays = nrc_amd.synthetic_rays(n_rays, seed=seed)
     jit = None if jitter_seed is None else [torch.from_numpy(j) for j in jitters(n_rays, seed=jitter_seed)]
     return cache_ref.material_model_cache_only(weights_torch(density_shift), cfg, rays_torch(rays, dtype), jit, **kw)
+
+
+def rays_dict_torch(rays: dict, dtype=torch.float32):
+    return {k: torch.from_numpy(np.asarray(v)).to(dtype) for k, v in rays.items()}
+
+
+def secondary_case(n, seed=5):
+    """Secondary rays as material.get_secondary_rays builds them (render_utils.py:927-1056): origins on
+    surfaces inside the scene offset along the normal, unit directions, near 0.05, far 2 (hotdog config),
+    plus explicit random inputs (per-level jitter, Gumbel noise)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    p = rng.normal(size=(n, 3))
+    p = p / np.linalg.norm(p, axis=-1, keepdims=True) * (0.9 * rng.uniform(size=(n, 1)) ** (1 / 3))
+    nrm = rng.normal(size=(n, 3))
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    rays = dict(origins=f32(p + 1e-2 * nrm), directions=f32(d), viewdirs=f32(d), near=f32(np.full((n, 1), 0.05)),
+                far=f32(np.full((n, 1), 2.0)), lights=f32(p), normals=f32(nrm), lossmult=f32(np.ones((n, 1))))
+    rnd = {"jitter": [rng.uniform(size=(n,)).astype(np.float32) for _ in range(3)],
+           "gumbel": rng.gumbel(size=(n, 32)).astype(np.float32)}
+    return rays, rnd

@@ -285,3 +285,80 @@ def test_render_image_matches_oracle_on_small_image():
     mse = float(np.mean((img["rgb"].reshape(360, 3) - ref["rgb"].numpy()) ** 2))
     psnr = -10.0 * np.log10(max(mse, 1e-30))
     assert err <= RGB_TOL and psnr >= 80.0, (err, psnr)
+
+
+# ---------------------------------------------------------------------------------------------
+# secondary rays (is_secondary=True): far clamp, near replacement, power-ladder distances,
+# categorical resampling to one sample, bg = 0, model-level EnvMap composite
+# ---------------------------------------------------------------------------------------------
+def _oracle_secondary(rays, rnd, **kw):
+    from oracle import cache_ref
+    jit = [torch.from_numpy(j)[:, None] for j in rnd["jitter"]]
+    return cache_ref.cache_forward(common.weights_torch(), nrc_amd.hotdog_config(), common.rays_dict_torch(rays), jit,
+                                   is_secondary=True, gumbel=torch.from_numpy(rnd["gumbel"]),
+                                   want_grad_normals=False, **kw)
+
+
+def test_secondary_rays_vs_oracle(rc):
+    from nrc_amd import rc_ext
+    n = 512
+    rays, rnd = common.secondary_case(n, seed=5)
+    ref = _oracle_secondary(rays, rnd)
+    out = rc.render_rays(rays, rnd, rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_SECONDARY)
+    torch.cuda.synchronize()
+    inds = rc.workspace("inds", np.int32)[:n]
+    ref_inds = ref["filtered_sampler_inds"][:, 0].numpy()
+    same = inds == ref_inds
+    assert same.mean() >= 0.995          # a Gumbel near-tie may flip under fp32 noise; none expected
+    r = ref["render"]
+    for l in range(3):
+        td = rc.workspace(f"tdist{l}").reshape(n, -1)
+        assert np.abs(td - ref["sampler"][l]["tdist"].numpy()).max() <= 2e-4
+        assert td.max() <= 2.0 + 1e-5 and td.min() >= 0.0          # far = min(far, env_map_distance)
+    for k in ("rgb", "acc", "diffuse_rgb", "specular_rgb", "indirect_rgb", "direct_rgb"):
+        v = out[k].cpu().numpy()
+        assert np.abs(v[same] - r[k].numpy().reshape(v.shape)[same]).max() <= RGB_TOL, k
+    assert np.abs(out["env_map_rgb"].cpu().numpy() - r["env_map_rgb"].numpy()).max() <= 1e-5
+    no_env = (r["rgb_no_stopgrad"] - r["env_map_rgb"] * (1 - r["acc"][:, None])).numpy()
+    assert np.abs(out["rgb_no_env"].cpu().numpy()[same] - no_env[same]).max() <= RGB_TOL
+    assert np.abs(out["distance_median"].cpu().numpy() - r["distance_median"].numpy()).max() <= 1e-3
+
+
+def test_secondary_rays_without_envmap_and_given_indices(rc):
+    from nrc_amd import rc_ext
+    n = 200
+    rays, rnd = common.secondary_case(n, seed=9)
+    ref = _oracle_secondary(rays, rnd, use_env_map=False)
+    # hand the oracle's picks over (filtered_sampler_inds): removes the only discontinuous step
+    rnd2 = dict(jitter=rnd["jitter"], resample_inds=ref["filtered_sampler_inds"][:, 0].numpy().astype(np.int32))
+    mask = rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_SECONDARY | rc_ext.RC_PASS_NO_ENVMAP
+    out = rc.render_rays(rays, rnd2, mask)
+    torch.cuda.synchronize()
+    r = ref["render"]
+    assert np.abs(out["rgb"].cpu().numpy() - r["rgb"].numpy()).max() <= RGB_TOL
+    assert np.abs(out["acc"].cpu().numpy() - r["acc"].numpy()).max() <= RGB_TOL
+    assert float(out["env_map_rgb"].abs().max()) == 0.0
+    assert np.array_equal(rc.workspace("inds", np.int32)[:n], rnd2["resample_inds"])
+
+
+def test_primary_rays_with_forced_resampling(rc):
+    """resample=True on primary rays (MaterialModel.resample_render, models.py:156-167): one shaded sample,
+    acc / distances from the unfiltered weights, bg = 1."""
+    from nrc_amd import rc_ext
+    from oracle import cache_ref
+    n = 256
+    rays = nrc_amd.synthetic_rays(n)
+    rng = np.random.Generator(np.random.PCG64(3))
+    g = rng.gumbel(size=(n, 32)).astype(np.float32)
+    ref = cache_ref.cache_forward(common.weights_torch(), nrc_amd.hotdog_config(), common.rays_torch(rays), None,
+                                  resample=True, gumbel=torch.from_numpy(g), want_grad_normals=False)
+    out = rc.render_rays(rays.hot_fields(), {"gumbel": g}, rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_RESAMPLE)
+    torch.cuda.synchronize()
+    same = rc.workspace("inds", np.int32)[:n] == ref["filtered_sampler_inds"][:, 0].numpy()
+    assert same.mean() >= 0.99
+    r = ref["render"]
+    # importance weights w/p amplify: compare relative to the magnitude of the estimate
+    v, b = out["rgb"].cpu().numpy()[same], r["rgb"].numpy()[same]
+    assert np.abs(v - b).max() <= 2e-4 * max(1.0, np.abs(b).max())
+    assert np.abs(out["acc"].cpu().numpy() - r["acc"].numpy()).max() <= RGB_TOL
+    assert np.abs(out["distance_median"].cpu().numpy() - r["distance_median"].numpy()).max() <= 1e-3
