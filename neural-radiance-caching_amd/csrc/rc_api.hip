@@ -331,6 +331,21 @@ int repack(rc_handle* h) {
     std::vector<Col> regs = {Col{dout, 0}};
     if (dn) { regs.push_back(Col{dn, 0}); regs.push_back(Col{dn, 1}); regs.push_back(Col{dn, 2}); }
     append(stream, pack(s, {tile_by_reg(regs)}));
+    if (dn) {
+      // backward fragments for the analytic normals (last level): w_out in accumulator layout, W1^T, W0^T
+      HostLayer w1t, w0t;
+      w1t.in = d1->out; w1t.out = d1->in; w1t.kernel.resize(d1->kernel.size()); w1t.bias.assign(w1t.out, 0.0f);
+      for (int r = 0; r < d1->in; ++r) for (int c2 = 0; c2 < d1->out; ++c2) w1t.kernel[(size_t)c2 * w1t.out + r] = d1->kernel[(size_t)r * d1->out + c2];
+      w0t.in = d0->out; w0t.out = d0->in; w0t.kernel.resize(d0->kernel.size()); w0t.bias.assign(w0t.out, 0.0f);
+      for (int r = 0; r < d0->in; ++r) for (int c2 = 0; c2 < d0->out; ++c2) w0t.kernel[(size_t)c2 * w0t.out + r] = d0->kernel[(size_t)r * d0->out + c2];
+      std::vector<float> wo(32 * 64);
+      for (int t = 0; t < 2; ++t) for (int r = 0; r < 16; ++r) for (int lane = 0; lane < 64; ++lane)
+        wo[(size_t)(t * 16 + r) * 64 + lane] = dout->kernel[(size_t)acc_feat(t, r, lane >> 5) * dout->out + 0];
+      append(stream, wo);
+      std::vector<Step> sb; steps_acc(sb, 2, 0);
+      append(stream, pack(sb, {tile_full(&w1t, 0, 0, false), tile_full(&w1t, 1, 0, false)}));
+      append(stream, pack(sb, {tile_full(&w0t, 0, 0, false)}));
+    }
     int rc = upload(h, "dens_" + std::to_string(l), pad_stream(stream));
     if (rc) return rc;
   }
@@ -473,6 +488,8 @@ int ensure_workspace(rc_handle* h, int64_t n) {
   const int64_t np = n * S2;
   if ((rc = ws_alloc(h, "hbuf", ((np + 31) / 32) * 32 * 64))) return rc;
   if ((rc = ws_alloc(h, "normals_pred", 3 * np))) return rc;
+  if ((rc = ws_alloc(h, "normals_grad", 3 * np))) return rc;
+  if ((rc = ws_alloc(h, "jac", 3 * 32 * np))) return rc;
   if ((rc = ws_alloc(h, "app", 32 * np))) return rc;
   if ((rc = ws_alloc(h, "shade", RC_SHADE_CH * np))) return rc;
   if ((rc = ws_alloc(h, "debug", 20 * ((np + 31) / 32) + 64))) return rc;
@@ -781,7 +798,9 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     rc_launch_sample(sa, st);
 
     stage_mark(h, slot, ST_GRID0 + 3 * l, st);
-    rc_launch_hashgrid(h->grids[l].dev, W(h, "means" + L), 1, np, W(h, "feat" + L), 1, np, c.contract_radius, nullptr, st);
+    const bool want_grad = (l == NL - 1) && A.out.ptr[RC_OUT_NORMALS] != nullptr;
+    rc_launch_hashgrid(h->grids[l].dev, W(h, "means" + L), 1, np, W(h, "feat" + L), 1, np, c.contract_radius,
+                       want_grad ? W(h, "jac") : nullptr, st);
 
     RcDensityMlpArgs da{};
     da.feat = W(h, "feat" + L); da.n = np; da.ld = np;
@@ -793,6 +812,8 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     da.density = W(h, "density" + L);
     da.hbuf = da.last ? W(h, "hbuf") : nullptr;
     da.normals_pred = da.last ? W(h, "normals_pred") : nullptr;
+    da.jac = want_grad ? W(h, "jac") : nullptr;
+    da.normals_grad = want_grad ? W(h, "normals_grad") : nullptr;
     stage_mark(h, slot, ST_MLP0 + 3 * l, st);
     rc_launch_density_mlp(da, st);
   }
@@ -832,7 +853,8 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     RcCompositeArgs ca{};
     ca.directions = rays->directions; ca.origins = rays->origins; ca.lights = rays->lights; ca.n_rays = n; ca.S = S2;
     ca.tdist = W(h, "tdist" + LL); ca.density = W(h, "density" + LL); ca.means = W(h, "means" + LL);
-    ca.normals_pred = W(h, "normals_pred"); ca.normals_grad = nullptr;
+    ca.normals_pred = W(h, "normals_pred");
+    ca.normals_grad = A.out.ptr[RC_OUT_NORMALS] ? W(h, "normals_grad") : nullptr;
     ca.shade = W(h, "shade"); ca.Sf = resample ? 1 : S2;
     ca.inds = resample ? (const int32_t*)W(h, "inds") : nullptr;
     ca.filt_weight = resample ? W(h, "filt_weight") : nullptr;

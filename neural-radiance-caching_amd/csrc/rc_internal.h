@@ -119,6 +119,8 @@ struct RcDensityMlpArgs {
   float* density;             // [n]
   float* hbuf;                // [n/32][32 steps][64] hidden feature in accumulator layout
   float* normals_pred;        // SoA [3][n]
+  const float* jac;           // [3][K][ld] d feature / d contracted coordinate (k_hashgrid_fwd<F, true>) or nullptr
+  float* normals_grad;        // SoA [3][n] analytic normals (needs jac; the stream must carry the backward fragments)
 };
 void rc_launch_density_mlp(const RcDensityMlpArgs& a, hipStream_t stream);
 

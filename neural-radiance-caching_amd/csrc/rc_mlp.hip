@@ -84,6 +84,13 @@ __device__ __forceinline__ void ws_advance(const WStream& w, int c) {
   if ((c + 1) * kChunk < NF) ws_issue<NF, W>(w, c + 1);
 }
 
+// Read fragment f of the stream as a per-lane value (used for lane-layout constant vectors).
+template <int NF, int W = kWaves>
+__device__ __forceinline__ float ws_read(const WStream& w, int f) {
+  if (f > 0 && f % kChunk == 0) ws_advance<NF, W>(w, f / kChunk);
+  return w.ring[(f % (2 * kChunk)) * 64 + w.lane];
+}
+
 // One pass over KS k-steps for NT output tiles; the layer's fragments are [FBASE, FBASE + KS*NT)
 // of the stream.  act: this lane's activation column (act[s * 64] is step s).
 // Software pipelined in groups of SG k-steps: the LDS reads (A fragments + B activations) of group
@@ -172,11 +179,16 @@ __device__ __forceinline__ void neg_normalize(float& x, float& y, float& z) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kDensActSteps = 33;
 
-template <int KS0>   // k-steps of layer 0 including the bias step
+// GRAD (last level only): also the analytic normals -normalize(d raw / d x) of geometry.py:421-460:
+// backward through the two hidden layers on the matrix cores (transposed weights, ReLU masks kept as
+// one bit per accumulator register), then the trilinear Jacobian emitted by k_hashgrid_fwd<F, true>
+// and the Jacobian of the contraction.
+template <int KS0, bool GRAD>   // KS0: k-steps of layer 0 including the bias step
 __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a) {
   __shared__ __attribute__((aligned(16))) float ring[kRingFloats];
   __shared__ float lds[kWaves][kDensActSteps * 64];
-  constexpr int F_D0 = 0, F_D1 = 2 * KS0, F_DO = 2 * KS0 + 66, NF = 2 * KS0 + 99;
+  constexpr int F_D0 = 0, F_D1 = 2 * KS0, F_DO = 2 * KS0 + 66, F_WO = F_DO + 33, F_B1 = F_WO + 32,
+                F_B0 = F_B1 + 64, NF = GRAD ? F_B0 + 32 : F_WO;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
   const int64_t p0 = tile * 32;
@@ -198,11 +210,24 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
   f32x16 acc[2];
   acc[0] = zero16(); acc[1] = zero16();
   mlp_layer<2, KS0, F_D0, NF>(ws, act, acc);
+  uint32_t m0 = 0, m1 = 0;           // ReLU masks, bit t*16+r
+  if constexpr (GRAD) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m0 |= (acc[t][r] > 0.0f ? 1u : 0u) << (t * 16 + r);
+  }
   park<2, true>(acc, act, 0);
   act[32 * 64] = h == 0 ? 1.0f : 0.0f;
 
   acc[0] = zero16(); acc[1] = zero16();
   mlp_layer<2, 33, F_D1, NF>(ws, act, acc);
+  if constexpr (GRAD) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m1 |= (acc[t][r] > 0.0f ? 1u : 0u) << (t * 16 + r);
+  }
   park<2, true>(acc, act, 0);
   if (a.last && a.hbuf && p0 < a.n) {
     // hidden feature handed to the shader in accumulator (= B operand) layout
@@ -217,18 +242,71 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
   out[0] = zero16();
   mlp_layer<1, 33, F_DO, NF>(ws, act, out);
 
+  float cx = 0.0f, cy = 0.0f, cz = 0.0f;   // contracted position
+  float zx = 0.0f, zy = 0.0f, zz = 0.0f;   // x / radius
+  if (valid) {
+    zx = a.means[p] / a.contract_radius; zy = a.means[a.n + p] / a.contract_radius; zz = a.means[2 * a.n + p] / a.contract_radius;
+    cx = a.means[p]; cy = a.means[a.n + p]; cz = a.means[2 * a.n + p];
+    contract3(cx, cy, cz, a.contract_radius);
+  }
   if (h == 0 && valid) {
     // convert_raw_density (geometry.py:318-341)
     const float raw = out[0][0];
-    float x = a.means[p], y = a.means[a.n + p], z = a.means[2 * a.n + p];
-    contract3(x, y, z, a.contract_radius);
-    const bool inside = (x > -a.bbox) & (x < a.bbox) & (y > -a.bbox) & (y < a.bbox) & (z > -a.bbox) & (z < a.bbox);
+    const bool inside = (cx > -a.bbox) & (cx < a.bbox) & (cy > -a.bbox) & (cy < a.bbox) & (cz > -a.bbox) & (cz < a.bbox);
     const float d = expf(fminf(fmaxf(raw + a.density_bias, -RC_FMAX), 70.0f));
     a.density[p] = inside ? d : 0.0f;
     if (a.last && a.normals_pred) {
       float gx = out[0][1], gy = out[0][2], gz = out[0][3];
       neg_normalize(gx, gy, gz);
       a.normals_pred[p] = gx; a.normals_pred[a.n + p] = gy; a.normals_pred[2 * a.n + p] = gz;
+    }
+  }
+
+  if constexpr (GRAD) {
+    // d raw / d h1 = w_out (accumulator-layout constant vector from the stream), masked by ReLU'(h1)
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const float wv = ws_read<NF>(ws, F_WO + s);
+      act[s * 64] = ((m1 >> s) & 1u) ? wv : 0.0f;
+    }
+    f32x16 g[2];
+    g[0] = zero16(); g[1] = zero16();
+    mlp_layer<2, 32, F_B1, NF>(ws, act, g);            // W1 . (.)   (transposed layer, no bias)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) act[(t * 16 + r) * 64] = ((m0 >> (t * 16 + r)) & 1u) ? g[t][r] : 0.0f;
+    f32x16 gf[1];
+    gf[0] = zero16();
+    mlp_layer<1, 32, F_B0, NF>(ws, act, gf);           // W0 . (.) -> d raw / d feature (32, accumulator layout)
+    // chain through the trilinear Jacobian: this lane owns features acc_feat(0, r, h)
+    float gw[3] = {0.0f, 0.0f, 0.0f};
+    if (valid) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) gw[ax] += gf[0][r] * a.jac[(int64_t)(ax * 32 + i) * a.ld + p];
+      }
+    }
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) gw[ax] += __shfl_xor(gw[ax], 32, 64);
+    if (h == 0 && valid) {
+      // Jacobian of contract at z = x / radius: w = s(m) z, s = (2 sqrt(m) - 1) / m, m = max(1, |z|^2)
+      const float msq = zx * zx + zy * zy + zz * zz;
+      float gzx = gw[0], gzy = gw[1], gzz = gw[2];
+      if (msq > 1.0f) {
+        const float rt = sqrtf(msq);
+        const float s = (2.0f * rt - 1.0f) / msq;
+        const float ds = (1.0f - rt) / (msq * msq);          // ds/dm
+        const float gz_dot = gw[0] * zx + gw[1] * zy + gw[2] * zz;
+        gzx = s * gw[0] + 2.0f * ds * gz_dot * zx;
+        gzy = s * gw[1] + 2.0f * ds * gz_dot * zy;
+        gzz = s * gw[2] + 2.0f * ds * gz_dot * zz;
+      }
+      float nx = gzx / a.contract_radius, ny = gzy / a.contract_radius, nz = gzz / a.contract_radius;
+      neg_normalize(nx, ny, nz);
+      a.normals_grad[p] = nx; a.normals_grad[a.n + p] = ny; a.normals_grad[2 * a.n + p] = nz;
     }
   }
 }
@@ -503,9 +581,12 @@ void rc_launch_density_mlp(const RcDensityMlpArgs& a, hipStream_t stream) {
   dim3 grid((unsigned)((tiles + kWaves - 1) / kWaves)), block(kWaves * 64);
   const int ks0 = (a.K + 1) / 2 + 1;
   switch (ks0) {
-    case 4: hipLaunchKernelGGL(k_density_mlp<4>, grid, block, 0, stream, a); break;
-    case 5: hipLaunchKernelGGL(k_density_mlp<5>, grid, block, 0, stream, a); break;
-    case 17: hipLaunchKernelGGL(k_density_mlp<17>, grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((k_density_mlp<4, false>), grid, block, 0, stream, a); break;
+    case 5: hipLaunchKernelGGL((k_density_mlp<5, false>), grid, block, 0, stream, a); break;
+    case 17:
+      if (a.jac && a.normals_grad) hipLaunchKernelGGL((k_density_mlp<17, true>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((k_density_mlp<17, false>), grid, block, 0, stream, a);
+      break;
     default: break;   // rejected by the host before getting here
   }
 }
