@@ -459,19 +459,9 @@ int ws_alloc(rc_handle* h, const std::string& name, int64_t count) {
 float* W(rc_handle* h, const std::string& name) { return h->ws[name].p; }
 
 int ensure_workspace(rc_handle* h, int64_t n) {
+  // ws_alloc only (re)allocates when a buffer is too small and always records the current element
+  // count, so after the largest batch has been seen this is allocation-free.
   const rc_config& c = h->cfg;
-  if (n <= h->ws_rays) {
-    // counts reflect the current batch
-    for (int l = 0; l < c.num_levels; ++l) {
-      const int64_t S = c.num_samples[l];
-      const std::string L = std::to_string(l);
-      h->ws_count["sdist" + L] = n * (S + 1); h->ws_count["tdist" + L] = n * (S + 1);
-      h->ws_count["means" + L] = 3 * n * S; h->ws_count["density" + L] = n * S; h->ws_count["weights" + L] = n * S;
-    }
-    const int64_t S2 = c.num_samples[c.num_levels - 1];
-    h->ws_count["normals_pred"] = 3 * n * S2; h->ws_count["shade"] = RC_SHADE_CH * n * S2;
-    return RC_OK;
-  }
   int rc;
   for (int l = 0; l < c.num_levels; ++l) {
     const int64_t S = c.num_samples[l];
@@ -499,7 +489,7 @@ int ensure_workspace(rc_handle* h, int64_t n) {
   if ((rc = ws_alloc(h, "inds", n))) return rc;
   if ((rc = ws_alloc(h, "src_idx", n))) return rc;
   if ((rc = ws_alloc(h, "filt_weight", n))) return rc;
-  h->ws_rays = n;
+  if (n > h->ws_rays) h->ws_rays = n;
   return RC_OK;
 }
 
