@@ -80,7 +80,15 @@ typedef struct {
   float bg_intensity;          /* VolumeIntegrator.bg_intensity_range (equal ends) */
   float percentiles[3];        /* (5, 50, 95) */
   int32_t num_resample;        /* 1 */
-  int32_t reserved[8];
+  /* material stage */
+  float diffuse_sample_fraction; /* MaterialMLP.diffuse_sample_fraction (0.5) */
+  float secondary_normal_eps;    /* Config.secondary_normal_eps (1e-2) */
+  float secondary_near;          /* MaterialMLP.near_min (5e-2) */
+  float secondary_far;           /* Config.secondary_far (2) */
+  float min_roughness;           /* 0.01 */
+  float default_F_0;             /* 0.04 */
+  float vmf_scale;               /* LightMLP.vmf_scale (20) */
+  int32_t num_vmf;               /* LightMLP.num_components (128) */
 } rc_config;
 
 /* One named parameter tensor.  `name` is the Flax tree path
@@ -153,6 +161,46 @@ typedef struct {
   float* ptr[RC_OUT_COUNT];    /* device pointers; NULL = not requested */
 } rc_outputs;
 
+/* ---- material stage (config 3): BaseMaterialModel.__call__ with use_material / use_light_sampler
+ * (internal/models.py:1144-1254, 1398-1694).  Explicit random inputs for everything the reference
+ * draws with jax.random on that path; Ks = round(K (1 - diffuse_fraction)), Kd = K - Ks, Kc = Kd / 2. */
+typedef struct {
+  const float* gumbel;            /* [n, S_last]  categorical pick of the shading sample (models.py:1418-1438) */
+  const float* vmf_noise;         /* [n, 128, 3]  N(0,1): LightMLP.get_vmfs means_random (light_sampler.py:142-144) */
+  const float* spec_u1;           /* [n, Ks]      RandomGenerator2D.sample for the GGX sampler (render_utils.py:322-352) */
+  const float* spec_u2;           /* [n, Ks] */
+  const float* cos_u1;            /* [n, Kc]      ... for the cosine sampler */
+  const float* cos_u2;            /* [n, Kc] */
+  const int32_t* vmf_lobe;        /* [n]          categorical lobe pick of sample_vmf_vars (render_utils.py:1360-1372) */
+  const float* vmf_v;             /* [n, Kd-Kc, 2] N(0,1) (render_utils.py:1409-1410) */
+  const float* vmf_tmp;           /* [n, Kd-Kc]   U[0,1) (render_utils.py:1413) */
+  const float* sec_jitter[RC_MAX_LEVELS];  /* [n*(Ks+Kd)] per level: jitter of the secondary rays, block [n*Ks | n*Kd] */
+  const float* sec_gumbel;        /* [n*(Ks+Kd), S_last] */
+} rc_material_randoms;
+
+typedef enum {
+  RC_MOUT_RGB = 0,                 /* [n,3] material_rgb */
+  RC_MOUT_ACC,                     /* [n]   */
+  RC_MOUT_DIRECT_RGB, RC_MOUT_INDIRECT_RGB, RC_MOUT_DIFFUSE_RGB, RC_MOUT_SPECULAR_RGB,
+  RC_MOUT_DIRECT_DIFFUSE_RGB, RC_MOUT_DIRECT_SPECULAR_RGB, RC_MOUT_INDIRECT_DIFFUSE_RGB,
+  RC_MOUT_INDIRECT_SPECULAR_RGB,   /* [n,3] each */
+  RC_MOUT_INDIRECT_OCC,            /* [n]   */
+  RC_MOUT_LIGHTING_IRRADIANCE,     /* [n,3] */
+  RC_MOUT_MATERIAL_ALBEDO,         /* [n,3] composited over all samples (models.py:1845-1912) */
+  RC_MOUT_MATERIAL_ROUGHNESS,      /* [n]   */
+  RC_MOUT_MATERIAL_METALNESS,      /* [n]   */
+  RC_MOUT_MATERIAL_F_0,            /* [n]   */
+  RC_MOUT_MEANS,                   /* [n,3] of the filtered sample */
+  RC_MOUT_NORMALS_TO_USE,          /* [n,3] */
+  RC_MOUT_RAY_DISTS,               /* [n]   */
+  RC_MOUT_LIGHT_DISTS,             /* [n]   */
+  RC_MOUT_COUNT
+} rc_mat_output_id;
+
+typedef struct {
+  float* ptr[RC_MOUT_COUNT];
+} rc_mat_outputs;
+
 /* -- lifecycle: replaces models.construct_model / model.init (internal/models.py:2323-2358) */
 int rc_create(const rc_config* cfg, int device, rc_handle** out);
 void rc_destroy(rc_handle* h);
@@ -167,6 +215,16 @@ int rc_load_weights(rc_handle* h, const rc_tensor_desc* descs, int32_t n);
  * (BaseMaterialModel.__call__ -> BaseNeRFModel.__call__, internal/models.py:1144-1254, 657-774). */
 int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n_rays, const rc_randoms* rnd,
                    uint32_t pass_mask, const rc_outputs* out, void* stream);
+
+/* -- model.apply(..., passes=("cache","light","material")) for the material stage: the cache pass on the
+ * primary rays (-> cache_out, the `cache_<k>` keys), one resampled shading point per ray, light sampler,
+ * BRDF importance sampling of K secondary rays per point, ONE batched secondary trace of n*K rays through
+ * the same cache kernels (is_secondary, resample, no env map) + the model-level EnvMap along the same
+ * rays, Monte-Carlo BRDF integration and the MaterialIntegrator composite (-> mat_out).
+ * rnd->jitter[] drives the primary rays (NULL: deterministic branch). */
+int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n_rays, const rc_randoms* rnd,
+                       const rc_material_randoms* mrnd, int32_t num_secondary_samples,
+                       const rc_outputs* cache_out, const rc_mat_outputs* mat_out, void* stream);
 
 /* -- single operators on the path (used by the parity tests and by the roofline bench)
  * HashEncoding.__call__ incl. the contraction (internal/grid_utils.py:808-905, coord.py:37-69):

@@ -77,10 +77,12 @@ struct rc_handle {
   std::map<std::string, HostLayer> layers;   // key: path without /kernel|/bias
   bool packed_dirty = true;
   bool have_envmap = false;
+  bool have_material = false;
   // packed MFMA fragments (device)
   std::map<std::string, DevBuf> packs;
   DevBuf ide_table;
-  // workspace
+  // workspace (ws_prefix selects the slot: "" primary rays, "s:" batched secondary trace)
+  std::string ws_prefix;
   int64_t ws_rays = 0;
   std::map<std::string, DevBuf> ws;
   std::map<std::string, int64_t> ws_count;
@@ -431,6 +433,22 @@ int repack(rc_handle* h) {
       if (rc) return rc;
     }
   }
+  {
+    // material / light heads run as plain per-point kernels on the Flax layout
+    h->have_material = true;
+    for (const char* pth : {"params/MaterialShader/bottleneck_layer", "params/MaterialShader/pred_brdf_layer",
+                            "params/LightSampler/layers_0", "params/LightSampler/layers_1", "params/LightSampler/output_layer"}) {
+      std::string miss;
+      const HostLayer* L = need(h, pth, miss);
+      if (!L) { h->have_material = false; continue; }
+      int rc = upload(h, std::string("raw:") + pth + "/kernel", L->kernel);
+      if (rc) return rc;
+      if ((rc = upload(h, std::string("raw:") + pth + "/bias", L->bias))) return rc;
+    }
+    for (int g = 4; g < 6; ++g)
+      for (size_t l = 0; l < h->grids[g].sizes.size(); ++l)
+        if (!h->grids[g].loaded[l]) h->have_material = false;
+  }
   if (!h->ide_table.p) {
     RcIdeTable tb;
     build_ide_table(tb);
@@ -445,7 +463,8 @@ int repack(rc_handle* h) {
 // ---------------------------------------------------------------------------------------------
 // Workspace
 // ---------------------------------------------------------------------------------------------
-int ws_alloc(rc_handle* h, const std::string& name, int64_t count) {
+int ws_alloc(rc_handle* h, const std::string& name0, int64_t count) {
+  const std::string name = h->ws_prefix + name0;
   DevBuf& b = h->ws[name];
   const size_t bytes = (size_t)count * sizeof(float);
   if (b.bytes < bytes) {
@@ -456,7 +475,7 @@ int ws_alloc(rc_handle* h, const std::string& name, int64_t count) {
   h->ws_count[name] = count;
   return RC_OK;
 }
-float* W(rc_handle* h, const std::string& name) { return h->ws[name].p; }
+float* W(rc_handle* h, const std::string& name) { return h->ws[h->ws_prefix + name].p; }
 
 int ensure_workspace(rc_handle* h, int64_t n) {
   // ws_alloc only (re)allocates when a buffer is too small and always records the current element
@@ -961,6 +980,153 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_random
   RC_HIP(h, hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
   h->graphs.push_back(e);
   RC_HIP(h, hipGraphLaunch(e.exec, st));
+  return RC_OK;
+}
+
+int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_randoms* rnd,
+                       const rc_material_randoms* mr, int32_t K, const rc_outputs* cache_out,
+                       const rc_mat_outputs* mat_out, void* stream_v) {
+  if (!h) return RC_ERR_INVALID_ARG;
+  if (!rays || !mr || !cache_out || !mat_out) return fail(h, RC_ERR_INVALID_ARG, "rc_render_material: null argument");
+  if (n < 0) return fail(h, RC_ERR_INVALID_ARG, "rc_render_material: negative n_rays");
+  if (n == 0) return RC_OK;
+  if (!rays->origins || !rays->directions || !rays->viewdirs || !rays->near || !rays->far)
+    return fail(h, RC_ERR_INVALID_ARG, "rc_render_material: origins/directions/viewdirs/near/far are required");
+  const rc_config& c = h->cfg;
+  const int Ks = (int)lround(K * (1.0 - (double)c.diffuse_sample_fraction));
+  const int Kd = (int)lround(K * (double)c.diffuse_sample_fraction);
+  const int Kc = (int)lround(0.5 * Kd);
+  if (K < 2 || Ks < 1 || Kd < 2 || Kc < 1 || Kd - Kc < 1 || Ks + Kd > 64)
+    return fail(h, RC_ERR_UNSUPPORTED, "rc_render_material: num_secondary_samples must give 1 <= Ks, 2 <= Kd, Ks + Kd <= 64");
+  if (c.num_vmf != 128) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_material: num_vmf must be 128");
+  if (!mr->gumbel || !mr->vmf_noise || !mr->spec_u1 || !mr->spec_u2 || !mr->cos_u1 || !mr->cos_u2 || !mr->vmf_lobe ||
+      !mr->vmf_v || !mr->vmf_tmp || !mr->sec_gumbel)
+    return fail(h, RC_ERR_INVALID_ARG, "rc_render_material: every rc_material_randoms member except sec_jitter is required");
+  RC_HIP(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream_v;
+  int rc;
+  if (h->packed_dirty) {
+    drop_graphs(h);
+    if ((rc = repack(h))) return rc;
+  }
+  if (!h->have_material) return fail(h, RC_ERR_MISSING_WEIGHT, "missing weight: params/MaterialShader/* or params/LightSampler/*");
+  if (!h->have_envmap) return fail(h, RC_ERR_MISSING_WEIGHT, "missing weight: params/Cache/EnvMap/*");
+  const int NL = c.num_levels;
+  const int S2 = c.num_samples[NL - 1];
+  const int64_t np2 = n * S2, nsec = n * (Ks + Kd);
+  h->ws_prefix = "";
+  if ((rc = ensure_workspace(h, n))) return rc;
+  if ((rc = ws_alloc(h, "m_pts", 3 * n)) || (rc = ws_alloc(h, "m_nrm", 3 * n)) || (rc = ws_alloc(h, "m_feat", 32 * n)) ||
+      (rc = ws_alloc(h, "m_mat", RC_MAT_CH * n)) || (rc = ws_alloc(h, "m_feat_all", 32 * np2)) ||
+      (rc = ws_alloc(h, "m_mat_all", RC_MAT_CH * np2)) || (rc = ws_alloc(h, "l_feat", 32 * n)) ||
+      (rc = ws_alloc(h, "l_vmf", (int64_t)128 * RC_VMF_CH * n)) || (rc = ws_alloc(h, "sec_origins", 3 * nsec)) ||
+      (rc = ws_alloc(h, "sec_dirs", 3 * nsec)) || (rc = ws_alloc(h, "sec_near", nsec)) || (rc = ws_alloc(h, "sec_far", nsec)) ||
+      (rc = ws_alloc(h, "sec_lights", 3 * nsec)) || (rc = ws_alloc(h, "sec_samples", RC_SMP_CH * nsec)) ||
+      (rc = ws_alloc(h, "m_local_view", 3 * n)) || (rc = ws_alloc(h, "sec_rgb", 3 * nsec)) ||
+      (rc = ws_alloc(h, "sec_acc", nsec)) || (rc = ws_alloc(h, "sec_env", 3 * nsec)))
+    return rc;
+  h->ws_prefix = "s:";
+  rc = ensure_workspace(h, nsec);
+  h->ws_prefix = "";
+  if (rc) return rc;
+  rc_shader_prepare();
+  const std::string LL = std::to_string(NL - 1);
+
+  // 1. cache pass on the primary rays (all samples shaded) -> cache_out
+  RenderArgs A{};
+  A.rays = *rays; A.have_rnd = rnd != nullptr; if (rnd) A.rnd = *rnd;
+  A.n = n; A.mask = RC_PASS_CACHE; A.out = *cache_out; A.slot = -1;
+  enqueue_all(h, A, st);
+
+  // 2. one shading sample per ray (MaterialModel.resample_render, models.py:1430-1439)
+  {
+    RcResampleArgs ra{};
+    ra.n_rays = n; ra.S = S2; ra.tdist = W(h, "tdist" + LL); ra.density = W(h, "density" + LL);
+    ra.directions = rays->directions; ra.gumbel = mr->gumbel; ra.inds_in = nullptr;
+    ra.inds_out = (int32_t*)W(h, "inds"); ra.filt_weight = W(h, "filt_weight"); ra.weights = W(h, "weights" + LL);
+    rc_launch_resample(ra, st);
+    hipLaunchKernelGGL(k_make_src, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const int32_t*)W(h, "inds"),
+                       (int32_t*)W(h, "src_idx"), n, S2);
+    RcMatPointsArgs pa{};
+    pa.n = n; pa.n_src = np2; pa.src = (const int32_t*)W(h, "src_idx"); pa.means = W(h, "means" + LL);
+    pa.normals = W(h, "normals_pred"); pa.pts = W(h, "m_pts"); pa.nrm = W(h, "m_nrm");
+    rc_launch_gather_points(pa, st);
+  }
+  auto raw = [&](const char* path, const char* leaf) { return h->packs[std::string("raw:") + path + "/" + leaf].p; };
+  // 3. material head at the shading point, and on all samples for the material-only composite
+  {
+    RcMatHeadArgs ma{};
+    ma.w0 = raw("params/MaterialShader/bottleneck_layer", "kernel"); ma.b0 = raw("params/MaterialShader/bottleneck_layer", "bias");
+    ma.w1 = raw("params/MaterialShader/pred_brdf_layer", "kernel"); ma.b1 = raw("params/MaterialShader/pred_brdf_layer", "bias");
+    ma.min_roughness = c.min_roughness;
+    rc_launch_hashgrid(h->grids[4].dev, W(h, "m_pts"), 0, n, W(h, "m_feat"), 0, 32, c.contract_radius, nullptr, st);
+    ma.n = n; ma.feat = W(h, "m_feat"); ma.mat = W(h, "m_mat");
+    rc_launch_material_head(ma, st);
+    rc_launch_hashgrid(h->grids[4].dev, W(h, "means" + LL), 1, np2, W(h, "m_feat_all"), 0, 32, c.contract_radius, nullptr, st);
+    ma.n = np2; ma.feat = W(h, "m_feat_all"); ma.mat = W(h, "m_mat_all");
+    rc_launch_material_head(ma, st);
+    rc_launch_material_composite_all(n, S2, W(h, "weights" + LL), W(h, "m_mat_all"), mat_out->ptr[RC_MOUT_MATERIAL_ALBEDO],
+                                     mat_out->ptr[RC_MOUT_MATERIAL_ROUGHNESS], mat_out->ptr[RC_MOUT_MATERIAL_METALNESS],
+                                     mat_out->ptr[RC_MOUT_MATERIAL_F_0], c.default_F_0, st);
+  }
+  // 4. light sampler: 128 vMF lobes per shading point
+  {
+    rc_launch_hashgrid(h->grids[5].dev, W(h, "m_pts"), 0, n, W(h, "l_feat"), 0, 32, c.contract_radius, nullptr, st);
+    RcLightHeadArgs la{};
+    la.n = n; la.feat = W(h, "l_feat");
+    la.w0 = raw("params/LightSampler/layers_0", "kernel"); la.b0 = raw("params/LightSampler/layers_0", "bias");
+    la.w1 = raw("params/LightSampler/layers_1", "kernel"); la.b1 = raw("params/LightSampler/layers_1", "bias");
+    la.w2 = raw("params/LightSampler/output_layer", "kernel"); la.b2 = raw("params/LightSampler/output_layer", "bias");
+    la.pts = W(h, "m_pts"); la.noise = mr->vmf_noise; la.vmf_scale = c.vmf_scale; la.vmf = W(h, "l_vmf");
+    rc_launch_light_head(la, st);
+  }
+  // 5. BRDF importance sampling -> secondary rays
+  {
+    RcBrdfSampleArgs sa{};
+    sa.n = n; sa.Ks = Ks; sa.Kd = Kd; sa.Kc = Kc;
+    sa.pts = W(h, "m_pts"); sa.nrm = W(h, "m_nrm"); sa.viewdirs = rays->viewdirs; sa.lights = rays->lights;
+    sa.mat = W(h, "m_mat"); sa.vmf = W(h, "l_vmf");
+    sa.spec_u1 = mr->spec_u1; sa.spec_u2 = mr->spec_u2; sa.cos_u1 = mr->cos_u1; sa.cos_u2 = mr->cos_u2;
+    sa.vmf_lobe = mr->vmf_lobe; sa.vmf_v = mr->vmf_v; sa.vmf_tmp = mr->vmf_tmp;
+    sa.normal_eps = c.secondary_normal_eps; sa.near = c.secondary_near; sa.far = c.secondary_far;
+    sa.sec_origins = W(h, "sec_origins"); sa.sec_dirs = W(h, "sec_dirs"); sa.sec_near = W(h, "sec_near");
+    sa.sec_far = W(h, "sec_far"); sa.sec_lights = W(h, "sec_lights"); sa.samples = W(h, "sec_samples");
+    sa.local_view = W(h, "m_local_view");
+    rc_launch_brdf_sample(sa, st);
+  }
+  // 6. ONE batched secondary trace through the cache (is_secondary, resample, use_env_map=False;
+  //    ref_rays.normals = None since MaterialMLP.shadow_eps_indirect = False) + EnvMap along the same rays
+  {
+    RenderArgs B{};
+    B.rays.origins = W(h, "sec_origins"); B.rays.directions = W(h, "sec_dirs"); B.rays.viewdirs = W(h, "sec_dirs");
+    B.rays.near = W(h, "sec_near"); B.rays.far = W(h, "sec_far"); B.rays.lights = W(h, "sec_lights"); B.rays.normals = nullptr;
+    B.have_rnd = true;
+    for (int l = 0; l < RC_MAX_LEVELS; ++l) B.rnd.jitter[l] = mr->sec_jitter[l];
+    B.rnd.gumbel = mr->sec_gumbel; B.rnd.resample_inds = nullptr;
+    B.n = nsec; B.mask = RC_PASS_CACHE | RC_PASS_SECONDARY | RC_PASS_NO_ENVMAP; B.slot = -1;
+    memset(&B.out, 0, sizeof(B.out));
+    B.out.ptr[RC_OUT_RGB] = W(h, "sec_rgb"); B.out.ptr[RC_OUT_ACC] = W(h, "sec_acc");
+    float* sec_dirs = W(h, "sec_dirs"); float* sec_env = W(h, "sec_env");
+    h->ws_prefix = "s:";
+    enqueue_all(h, B, st);
+    h->ws_prefix = "";
+    RcEnvMapArgs ea{};
+    ea.n = nsec; ea.viewdirs = sec_dirs; ea.wstream = h->packs["envmap"].p; ea.rgb_bias = c.env_rgb_bias; ea.env_rgb = sec_env;
+    rc_launch_envmap(ea, st);
+  }
+  // 7. Monte-Carlo BRDF integration + MaterialIntegrator composite
+  {
+    RcMatIntegrateArgs ia{};
+    ia.n = n; ia.Ks = Ks; ia.Kd = Kd; ia.S = S2;
+    ia.mat = W(h, "m_mat"); ia.samples = W(h, "sec_samples"); ia.local_view = W(h, "m_local_view");
+    ia.sec_rgb = W(h, "sec_rgb"); ia.sec_acc = W(h, "sec_acc"); ia.sec_env = W(h, "sec_env");
+    ia.weights = W(h, "weights" + LL); ia.filt_weight = W(h, "filt_weight");
+    ia.pts = W(h, "m_pts"); ia.nrm = W(h, "m_nrm"); ia.origins = rays->origins; ia.lights = rays->lights;
+    ia.f0 = c.default_F_0; ia.rgb_max = c.rgb_max; ia.bg = c.bg_intensity;
+    ia.out = *mat_out;
+    rc_launch_material_integrate(ia, st);
+  }
+  RC_HIP(h, hipGetLastError());
   return RC_OK;
 }
 

@@ -158,3 +158,58 @@ struct RcIdeTable {
   int32_t m[RC_IDE_TERMS];
   float sigma[RC_IDE_TERMS];
 };
+
+// ---------------------------------------------------------------------------------------------
+// Material stage (rc_material.hip)
+// ---------------------------------------------------------------------------------------------
+enum { RC_MAT_CH = 5 };   // per point: albedo rgb, roughness, metalness
+enum { RC_VMF_CH = 5 };   // per lobe: normalised mean xyz, kappa, softmax weight
+enum { RC_SMP_CH = 5 };   // per secondary sample: local light dir xyz, pdf, MIS weight
+
+struct RcMatPointsArgs {
+  int64_t n, n_src; const int32_t* src; const float* means; const float* normals;   // SoA [3][n_src]
+  float* pts; float* nrm;                                                            // AoS [n,3]
+};
+void rc_launch_gather_points(const RcMatPointsArgs& a, hipStream_t st);
+
+struct RcMatHeadArgs {
+  int64_t n; const float* feat;        // row-major [n,32] material-grid features
+  const float* w0; const float* b0;    // Flax kernel [32,128], bias
+  const float* w1; const float* b1;    // [128,10]
+  float min_roughness; float* mat;     // [n, RC_MAT_CH]
+};
+void rc_launch_material_head(const RcMatHeadArgs& a, hipStream_t st);
+void rc_launch_material_composite_all(int64_t n, int S, const float* weights, const float* mat, float* out_albedo,
+                                      float* out_rough, float* out_metal, float* out_f0, float f0, hipStream_t st);
+
+struct RcLightHeadArgs {
+  int64_t n; const float* feat;        // [n,32] light-grid features
+  const float* w0; const float* b0; const float* w1; const float* b1; const float* w2; const float* b2;
+  const float* pts; const float* noise;   // [n,3], [n,128,3]
+  float vmf_scale; float* vmf;         // [n,128,RC_VMF_CH]
+};
+void rc_launch_light_head(const RcLightHeadArgs& a, hipStream_t st);
+
+struct RcBrdfSampleArgs {
+  int64_t n; int32_t Ks, Kd, Kc;
+  const float* pts; const float* nrm; const float* viewdirs; const float* lights; const float* mat; const float* vmf;
+  const float* spec_u1; const float* spec_u2; const float* cos_u1; const float* cos_u2;
+  const int32_t* vmf_lobe; const float* vmf_v; const float* vmf_tmp;
+  float normal_eps, near, far;
+  float* sec_origins; float* sec_dirs; float* sec_near; float* sec_far; float* sec_lights;   // [n*(Ks+Kd), .]
+  float* samples;       // [n, Ks+Kd, RC_SMP_CH]
+  float* local_view;    // [n,3]
+};
+void rc_launch_brdf_sample(const RcBrdfSampleArgs& a, hipStream_t st);
+
+struct RcMatIntegrateArgs {
+  int64_t n; int32_t Ks, Kd, S;
+  const float* mat; const float* samples; const float* local_view;
+  const float* sec_rgb; const float* sec_acc; const float* sec_env;
+  const float* weights;       // [n,S] unfiltered weights of the primary rays
+  const float* filt_weight;   // [n]
+  const float* pts; const float* nrm; const float* origins; const float* lights;
+  float f0, rgb_max, bg;
+  rc_mat_outputs out;
+};
+void rc_launch_material_integrate(const RcMatIntegrateArgs& a, hipStream_t st);

@@ -98,7 +98,7 @@ class Model:
         if sampling_strategy is not None and tuple(sampling_strategy) != tuple(self.config.sampling_strategy):
             raise NotImplementedError("sampling_strategy is fixed when the handle is created")
         if "material" in passes:
-            raise NotImplementedError("material pass: not part of this build (SURVEY.md §8, config 3)")
+            return self._apply_material(variables, rng, rays)
         if variables is not None and id(variables) != self._variables_id:
             self.load_variables(variables)
         fields = rays.hot_fields() if isinstance(rays, Rays) else dict(rays)
@@ -125,6 +125,40 @@ class Model:
         return {"render": render, "main": {"integrator": render}, "cache_main": {"integrator": render}}
 
     __call__ = apply
+
+    def _apply_material(self, variables, rng, rays):
+        """passes ("cache", "light", "material") with use_material / use_light_sampler /
+        MaterialModel.resample_render (stage material_light_from_scratch_resample; internal/models.py:1144-1254,
+        1398-1694).  `rng` must be the dict of explicit random tensors (see rc_material_randoms in
+        include/rc_abi.h; oracle-compatible generator: oracle.material_ref.draw_randoms)."""
+        import torch
+
+        if not isinstance(rng, dict) or "vmf_noise" not in rng:
+            raise ValueError("the material stage needs explicit random tensors: pass rng as the dict described "
+                             "by rc_material_randoms (jax.random is not reproduced)")
+        if variables is not None and id(variables) != self._variables_id:
+            self.load_variables(variables)
+        fields = rays.hot_fields() if isinstance(rays, Rays) else dict(rays)
+        cres, mres = self.rc.render_material(fields, rng)
+        cache = self._finalize(cres, fields)
+        r = dict(mres)
+        zeros3 = torch.zeros_like(r["rgb"])
+        for k in ("indirect_occ", "material_roughness", "material_metalness", "material_F_0", "ray_dists", "light_dists"):
+            r[k] = r[k][:, None]
+        r["material_diffuseness"] = torch.zeros_like(r["material_F_0"])     # constants of the configured
+        r["material_mirrorness"] = torch.zeros_like(r["material_F_0"])      # microfacet material
+        r["occ"] = zeros3
+        for k in ("distance_mean", "distance_median", "distance_percentile_5", "distance_percentile_95"):
+            r[k] = cache[k]
+        for k, v in cache.items():
+            if k.startswith("cache_"):
+                r[k] = v
+        r["material_rgb"] = r["rgb"]
+        r["normals"] = cache["normals"]
+        r["normals_pred"] = cache["normals_pred"]
+        r["vignette"] = torch.ones_like(r["rgb"][:, :1])
+        r["lossmult"] = torch.ones_like(r["rgb"][:, :1])
+        return {"render": r, "main": {"integrator": r}, "cache_main": {"integrator": cache}}
 
     def _finalize(self, dev: Dict[str, Any], fields) -> Dict[str, Any]:
         """Integrator keys + the aliases/constants of _finalize_outputs (internal/models.py:2074-2171)."""

@@ -49,7 +49,10 @@ class rc_config(C.Structure):
         ("contract_radius", C.c_float), ("roughness_bias", C.c_float), ("irradiance_bias", C.c_float),
         ("ambient_irradiance_bias", C.c_float), ("rgb_max", C.c_float), ("slf_ambient_bias", C.c_float),
         ("env_rgb_bias", C.c_float), ("env_map_distance", C.c_float), ("bg_intensity", C.c_float),
-        ("percentiles", C.c_float * 3), ("num_resample", C.c_int32), ("reserved", C.c_int32 * 8),
+        ("percentiles", C.c_float * 3), ("num_resample", C.c_int32),
+        ("diffuse_sample_fraction", C.c_float), ("secondary_normal_eps", C.c_float), ("secondary_near", C.c_float),
+        ("secondary_far", C.c_float), ("min_roughness", C.c_float), ("default_F_0", C.c_float),
+        ("vmf_scale", C.c_float), ("num_vmf", C.c_int32),
     ]
 
 
@@ -70,10 +73,32 @@ class rc_outputs(C.Structure):
     _fields_ = [("ptr", C.c_void_p * RC_OUT_COUNT)]
 
 
+# rc_mat_output_id -> (name, width); order must match include/rc_abi.h
+MAT_OUTPUTS = (
+    ("rgb", 3), ("acc", 1), ("direct_rgb", 3), ("indirect_rgb", 3), ("diffuse_rgb", 3), ("specular_rgb", 3),
+    ("direct_diffuse_rgb", 3), ("direct_specular_rgb", 3), ("indirect_diffuse_rgb", 3), ("indirect_specular_rgb", 3),
+    ("indirect_occ", 1), ("lighting_irradiance", 3), ("material_albedo", 3), ("material_roughness", 1),
+    ("material_metalness", 1), ("material_F_0", 1), ("means", 3), ("normals_to_use", 3), ("ray_dists", 1),
+    ("light_dists", 1),
+)
+MAT_OUTPUT_ID = {name: i for i, (name, _) in enumerate(MAT_OUTPUTS)}
+RC_MOUT_COUNT = len(MAT_OUTPUTS)
+
+
+class rc_material_randoms(C.Structure):
+    _fields_ = [("gumbel", C.c_void_p), ("vmf_noise", C.c_void_p), ("spec_u1", C.c_void_p), ("spec_u2", C.c_void_p),
+                ("cos_u1", C.c_void_p), ("cos_u2", C.c_void_p), ("vmf_lobe", C.c_void_p), ("vmf_v", C.c_void_p),
+                ("vmf_tmp", C.c_void_p), ("sec_jitter", C.c_void_p * RC_MAX_LEVELS), ("sec_gumbel", C.c_void_p)]
+
+
+class rc_mat_outputs(C.Structure):
+    _fields_ = [("ptr", C.c_void_p * RC_MOUT_COUNT)]
+
+
 EXPORTS = (
     "rc_create", "rc_destroy", "rc_last_error", "rc_abi_version", "rc_load_weights", "rc_render_rays",
     "rc_hashgrid_lookup", "rc_sample_intervals", "rc_workspace_ptr", "rc_set_profiling", "rc_stage_count",
-    "rc_stage_name", "rc_stage_times_ms", "rc_set_graph_mode",
+    "rc_stage_name", "rc_stage_times_ms", "rc_set_graph_mode", "rc_render_material",
 )
 
 _LIB = None
@@ -106,6 +131,10 @@ def load_library():
     lib.rc_render_rays.argtypes = [C.c_void_p, C.POINTER(rc_rays), C.c_int64, C.POINTER(rc_randoms), C.c_uint32,
                                    C.POINTER(rc_outputs), C.c_void_p]
     lib.rc_render_rays.restype = C.c_int
+    lib.rc_render_material.argtypes = [C.c_void_p, C.POINTER(rc_rays), C.c_int64, C.POINTER(rc_randoms),
+                                       C.POINTER(rc_material_randoms), C.c_int32, C.POINTER(rc_outputs),
+                                       C.POINTER(rc_mat_outputs), C.c_void_p]
+    lib.rc_render_material.restype = C.c_int
     lib.rc_hashgrid_lookup.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
     lib.rc_hashgrid_lookup.restype = C.c_int
     lib.rc_sample_intervals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
@@ -149,6 +178,10 @@ def config_to_c(cfg: RenderConfig) -> rc_config:
     for i, p in enumerate(cfg.percentiles):
         c.percentiles[i] = float(p)
     c.num_resample = cfg.num_resample
+    for k in ("diffuse_sample_fraction", "secondary_normal_eps", "secondary_near", "secondary_far", "min_roughness",
+              "default_F_0", "vmf_scale"):
+        setattr(c, k, float(getattr(cfg, k)))
+    c.num_vmf = cfg.num_vmf
     return c
 
 
@@ -279,6 +312,66 @@ class RadianceCache:
         self._check(self.lib.rc_render_rays(self._h, C.byref(r), n, rnd_p, pass_mask, C.byref(cout), stream))
         self._keep = [held]   # keep inputs alive until the next call (async enqueue)
         return res
+
+    def _rays_struct(self, rays):
+        r = rc_rays()
+        held = {}
+        n = None
+        for k in ("origins", "directions", "viewdirs", "near", "far", "lights", "normals"):
+            v = rays.get(k)
+            if v is None:
+                continue
+            t = self._dev(v)
+            t = t.reshape(-1, 3) if k not in ("near", "far") else t.reshape(-1)
+            held[k] = t
+            setattr(r, k, t.data_ptr())
+            n = t.shape[0] if n is None else n
+            if t.shape[0] != n:
+                raise ValueError(f"ray field {k} has {t.shape[0]} rows, expected {n}")
+        return r, held, n
+
+    def render_material(self, rays: Dict[str, object], randoms: Dict[str, object], num_secondary_samples: int = None):
+        """Material stage (rc_render_material).  randoms: dict with the keys of
+        oracle-compatible `draw_randoms` (jitter[3], gumbel, vmf_noise, spec_u1/u2, cos_u1/u2, vmf_lobe, vmf_v,
+        vmf_tmp, spec_jitter[3], spec_gumbel, diff_jitter[3], diff_gumbel).
+        Returns (cache_outputs, material_outputs) as dicts of cuda tensors."""
+        torch = self._torch
+        K = num_secondary_samples or self.cfg.num_secondary_samples
+        r, held, n = self._rays_struct(rays)
+        dev = f"cuda:{self.device}"
+        rnd = rc_randoms()
+        if randoms.get("jitter") is not None:
+            for l, j in enumerate(randoms["jitter"]):
+                held[f"jit{l}"] = self._dev(j).reshape(-1)
+                rnd.jitter[l] = held[f"jit{l}"].data_ptr()
+        mr = rc_material_randoms()
+        for k in ("gumbel", "vmf_noise", "spec_u1", "spec_u2", "cos_u1", "cos_u2", "vmf_v", "vmf_tmp"):
+            held["m_" + k] = self._dev(randoms[k])
+            setattr(mr, k, held["m_" + k].data_ptr())
+        held["m_lobe"] = self._dev(randoms["vmf_lobe"], torch.int32).reshape(-1)
+        mr.vmf_lobe = held["m_lobe"].data_ptr()
+        # secondary trace randoms: [specular block | diffuse block]
+        for l in range(RC_MAX_LEVELS):
+            held[f"sj{l}"] = torch.cat([self._dev(randoms["spec_jitter"][l]).reshape(-1),
+                                        self._dev(randoms["diff_jitter"][l]).reshape(-1)])
+            mr.sec_jitter[l] = held[f"sj{l}"].data_ptr()
+        held["sg"] = torch.cat([self._dev(randoms["spec_gumbel"]), self._dev(randoms["diff_gumbel"])], dim=0).contiguous()
+        mr.sec_gumbel = held["sg"].data_ptr()
+        cout, mout = rc_outputs(), rc_mat_outputs()
+        cres, mres = {}, {}
+        for i, (nm, width) in enumerate(OUTPUTS):
+            if nm in ("env_map_rgb", "rgb_no_env"):
+                continue
+            cres[nm] = torch.zeros((n, 3) if width == 3 else (n,), dtype=torch.float32, device=dev)
+            cout.ptr[i] = cres[nm].data_ptr()
+        for i, (nm, width) in enumerate(MAT_OUTPUTS):
+            mres[nm] = torch.zeros((n, 3) if width == 3 else (n,), dtype=torch.float32, device=dev)
+            mout.ptr[i] = mres[nm].data_ptr()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.rc_render_material(self._h, C.byref(r), n, C.byref(rnd), C.byref(mr), K, C.byref(cout),
+                                                C.byref(mout), stream))
+        self._keep = [held]
+        return cres, mres
 
     # -- single operators ---------------------------------------------------------------------
     def hashgrid_lookup(self, grid_id: int, points, apply_contraction: bool = True):

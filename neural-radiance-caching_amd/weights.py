@@ -88,10 +88,14 @@ def param_shapes(cfg: RenderConfig, passes: Tuple[str, ...] = ("cache",)) -> "Or
 
 
 def synthetic_weights(cfg: RenderConfig, passes=("cache",), seed: int = 1, density_shift: float = 0.0,
-                      table_range: float = 0.05) -> Dict[str, np.ndarray]:
+                      table_range: float = 0.05, level_decay: float = 1.0) -> Dict[str, np.ndarray]:
     """Seeded synthetic weights: tables U(+-table_range), dense kernels
     He-uniform U(+-sqrt(6/fan_in)), biases U(+-0.1).  `density_shift` is added to the
     output_density_layer biases (the "shell" set uses +4 so rays saturate).
+    `level_decay` < 1 scales the table of grid level l by level_decay**l: with 0.5 every level
+    contributes the same spatial gradient (like a trained multiresolution field) instead of the
+    white-noise field of level_decay = 1, whose fine levels amplify one-ulp position differences
+    by N = 2048 ("smooth" set of the strict parity tests).
 
     There is no trained checkpoint in the build environment; these stand in for one.
     """
@@ -100,7 +104,8 @@ def synthetic_weights(cfg: RenderConfig, passes=("cache",), seed: int = 1, densi
     for name, shape in param_shapes(cfg, passes).items():
         leaf = name.rsplit("/", 1)[-1]
         if leaf.startswith(("grid_", "hash_")):
-            a = rng.uniform(-table_range, table_range, size=shape)
+            level = int(round(np.log2(int(leaf.split("_")[1]) / 16.0)))
+            a = rng.uniform(-table_range, table_range, size=shape) * (level_decay ** level)
         elif leaf == "kernel":
             lim = np.sqrt(6.0 / shape[0])
             a = rng.uniform(-lim, lim, size=shape)

@@ -13,6 +13,19 @@ def weights_np(density_shift=0.0, seed=1):
     return nrc_amd.synthetic_weights(nrc_amd.hotdog_config(), seed=seed, density_shift=density_shift)
 
 
+@functools.lru_cache(maxsize=2)
+def weights_material_np(smooth=False):
+    """Cache + material + light weights.  smooth=True: table amplitude 0.2 * 0.5**level (equal spatial
+    gradient per level) -- removes the chaotic amplification of one-ulp position differences that random
+    fine-level tables cause, so the two implementations can be compared tightly."""
+    kw = dict(level_decay=0.5, table_range=0.2) if smooth else {}
+    return nrc_amd.synthetic_weights(nrc_amd.hotdog_config(), passes=("cache", "material"), **kw)
+
+
+def to_torch(w, dtype=None):
+    return {k: (torch.from_numpy(v) if dtype is None else torch.from_numpy(v).to(dtype)) for k, v in w.items()}
+
+
 def weights_torch(density_shift=0.0, seed=1, dtype=None):
     w = weights_np(density_shift, seed)
     return {k: (torch.from_numpy(v) if dtype is None else torch.from_numpy(v).to(dtype)) for k, v in w.items()}
