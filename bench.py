@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph-mode", type=int, default=2, help="0 eager, 1 lazy hipGraph, 2 hipGraph at once")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent batches in flight: step i is enqueued on HIP stream i %% streams")
     ap.add_argument("--profile-mode", type=int, default=2,
                     help="events in the timed region: 0 none, 1 every stage, 2 dominant kernel only")
     args = ap.parse_args()
@@ -106,12 +108,25 @@ def main():
     rays["far"] = rays["far"].reshape(-1)
     rays.pop("lossmult", None)
 
-    out = rc.render_rays(rays, None, outputs=_CACHE_DEVICE_KEYS)
+    nstr = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstr)] if nstr > 1 else [torch.cuda.current_stream(dev)]
+    outs = []
+    for s_ in streams:
+        with torch.cuda.stream(s_):
+            outs.append(rc.render_rays(rays, None, outputs=_CACHE_DEVICE_KEYS))
+    torch.cuda.synchronize()
+    out = outs[0]
+
+    def step(i):
+        with torch.cuda.stream(streams[i % nstr]):
+            rc.render_rays(rays, None, out=outs[i % nstr])
+
     # Timed region: two HIP events per step around the dominant kernel only (each event record costs
     # a few us of GPU timeline, so the full per-stage profile is taken in a separate pass below).
     rc.set_profiling(args.profile_mode)
-    for _ in range(args.warmup):
-        rc.render_rays(rays, None, out=out)
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
     rc.set_profiling(args.profile_mode)          # reset the event ring
 
     def barrier():
@@ -121,8 +136,8 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rc.render_rays(rays, None, out=out)
+    for i in range(args.steps):
+        step(i)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -137,7 +152,7 @@ def main():
     # separate pass: every stage bracketed by events (not part of `value`)
     rc.set_profiling(1)
     for _ in range(16):
-        rc.render_rays(rays, None, out=out)
+        rc.render_rays(rays, None, out=out)      # single stream: undisturbed per-stage times
     torch.cuda.synchronize()
     stage = rc.stage_times_ms()
     if rank != 0:
@@ -160,7 +175,8 @@ def main():
         "config": {"workload": "hotdog cache render 1024 rays x (64,64,32) samples, cache-only passes, "
                                "synthetic rays + synthetic weights (configs[1])",
                    "rays_per_batch_per_gpu": RAYS_PER_BATCH, "parallelism": f"ray-sharded x{world}",
-                   "launch": "eager" if (args.profile_mode or args.graph_mode == 0) else "hipGraph"},
+                   "launch": "eager" if (args.profile_mode or args.graph_mode == 0) else "hipGraph",
+                   "batches_in_flight": nstr},
         "roofline": {"kernel": "k_cache_shader", "bound": "mfma", "achieved": achieved_tf,
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
                      # HBM-side bytes per launch from the rocprofv3 PMC passes kept under profiles/

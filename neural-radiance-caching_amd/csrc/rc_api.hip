@@ -48,7 +48,7 @@ constexpr int kEvSlots = 16;
 
 // Everything that is baked into the kernel arguments of one rc_render_rays call.
 struct RenderKey {
-  int64_t n; uint32_t mask; int slot;
+  int64_t n; uint32_t mask; int slot; int ws_slot;
   const void* rays[7]; const void* rnd[RC_MAX_LEVELS + 2]; const void* out[RC_OUT_COUNT];
   bool operator==(const RenderKey& o) const { return memcmp(this, &o, sizeof(RenderKey)) == 0; }
 };
@@ -81,8 +81,10 @@ struct rc_handle {
   // packed MFMA fragments (device)
   std::map<std::string, DevBuf> packs;
   DevBuf ide_table;
-  // workspace (ws_prefix selects the slot: "" primary rays, "s:" batched secondary trace)
+  // workspace (ws_prefix selects the slot: "" / "p1:".. one per caller stream so that independent
+  // batches enqueued on different streams overlap; "s:" batched secondary trace of the material stage)
   std::string ws_prefix;
+  std::vector<hipStream_t> slot_streams;
   int64_t ws_rays = 0;
   std::map<std::string, DevBuf> ws;
   std::map<std::string, int64_t> ws_count;
@@ -918,7 +920,23 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_random
   }
   if (secondary && !(pass_mask & RC_PASS_NO_ENVMAP) && !h->have_envmap)
     return fail(h, RC_ERR_MISSING_WEIGHT, "missing weight: params/Cache/EnvMap/* (secondary rays composite the model-level EnvMap)");
-  if (n > h->ws_rays) drop_graphs(h);
+  // one workspace slot per caller stream (up to 4): calls on different streams do not share buffers
+  int ws_slot = 0;
+  {
+    size_t i = 0;
+    for (; i < h->slot_streams.size(); ++i) if (h->slot_streams[i] == st) break;
+    if (i == h->slot_streams.size()) {
+      if (h->slot_streams.size() < 4) h->slot_streams.push_back(st);
+      else i = 0;   // more than 4 streams: fall back to the first slot (stream order then serialises)
+    }
+    ws_slot = (int)i;
+  }
+  struct PrefixGuard {
+    rc_handle* h;
+    ~PrefixGuard() { h->ws_prefix = ""; }
+  } guard{h};
+  h->ws_prefix = ws_slot == 0 ? "" : "p" + std::to_string(ws_slot) + ":";
+  if (h->ws_count.find(h->ws_prefix + "acc_ws") == h->ws_count.end() || h->ws_count[h->ws_prefix + "acc_ws"] < n) drop_graphs(h);
   if ((rc = ensure_workspace(h, n))) return rc;
   rc_shader_prepare();
 
@@ -940,7 +958,7 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_random
   }
   RenderKey key;
   memset(&key, 0, sizeof(key));
-  key.n = n; key.mask = pass_mask; key.slot = A.slot;
+  key.n = n; key.mask = pass_mask; key.slot = A.slot; key.ws_slot = ws_slot;
   const void* rp[7] = {rays->origins, rays->directions, rays->viewdirs, rays->near, rays->far, rays->lights, rays->normals};
   memcpy(key.rays, rp, sizeof(rp));
   if (rnd) {

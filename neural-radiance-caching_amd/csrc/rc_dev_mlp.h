@@ -1,0 +1,303 @@
+// Device-side building blocks of the MFMA MLP kernels (shared by rc_mlp.hip and rc_fused.hip).
+// See rc_mlp.hip for the formulation (transposed fp32 MFMA, weight stream through an LDS ring).
+#pragma once
+#include "rc_internal.h"
+
+namespace rcdev {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWaves = 4;   // waves per workgroup; each wave owns 32 points
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+  return z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight stream.  All MLP layers of a kernel are packed by the host into ONE linear stream of
+// 256-byte MFMA A-fragments in exactly the order the kernel consumes them.  The workgroup pulls
+// the stream through a two-chunk LDS ring with LDS-DMA (global_load_lds_dwordx4, no VGPRs): while
+// the waves run the MFMAs of chunk c out of LDS, chunk c+1 is in flight.  One barrier per chunk
+// (kChunk fragments = kChunk MFMAs per wave) is the only synchronisation; every wave of the
+// workgroup executes the identical, fully unrolled fragment sequence.
+// ---------------------------------------------------------------------------------------------
+constexpr int kChunk = 64;                       // fragments per chunk (16 KiB)
+constexpr int kRingFloats = 2 * kChunk * 64;     // two chunks
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+struct WStream {
+  const float* g;    // packed fragment stream (padded to a whole number of chunks)
+  float* ring;       // LDS ring [2 * kChunk][64]
+  int lane, wave;
+};
+
+// Issue the LDS-DMA of chunk c (this wave's quarter: 4 x 1 KiB).
+template <int NF, int W = kWaves>
+__device__ __forceinline__ void ws_issue(const WStream& w, int c) {
+#pragma unroll
+  for (int k = 0; k < kChunk / 4 / W; ++k) {
+    const int i = w.wave + W * k;                  // 1-KiB piece inside the chunk
+    const int frag0 = c * kChunk + 4 * i;
+    if (frag0 < NF) {
+      const float* src = w.g + (size_t)frag0 * 64 + w.lane * 4;
+      float* dst = w.ring + ((c & 1) * kChunk + 4 * i) * 64;
+      __builtin_amdgcn_global_load_lds((const void*)src, (lds_void_ptr)dst, 16, 0, 0);
+    }
+  }
+}
+
+template <int NF, int W = kWaves>
+__device__ __forceinline__ void ws_begin(const WStream& w) {
+  ws_issue<NF, W>(w, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (kChunk < NF) ws_issue<NF, W>(w, 1);
+}
+
+// Entering chunk c: it has landed (issued one chunk ago), everybody is done with chunk c-1.
+template <int NF, int W = kWaves>
+__device__ __forceinline__ void ws_advance(const WStream& w, int c) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if ((c + 1) * kChunk < NF) ws_issue<NF, W>(w, c + 1);
+}
+
+// Read fragment f of the stream as a per-lane value (used for lane-layout constant vectors).
+template <int NF, int W = kWaves>
+__device__ __forceinline__ float ws_read(const WStream& w, int f) {
+  if (f > 0 && f % kChunk == 0) ws_advance<NF, W>(w, f / kChunk);
+  return w.ring[(f % (2 * kChunk)) * 64 + w.lane];
+}
+
+// One pass over KS k-steps for NT output tiles; the layer's fragments are [FBASE, FBASE + KS*NT)
+// of the stream.  act: this lane's activation column (act[s * 64] is step s).
+// Software pipelined in groups of SG k-steps: the LDS reads (A fragments + B activations) of group
+// g+1 are issued before the MFMAs of group g, with scheduling fences so they stay there; the MFMA
+// pipe then runs back to back while the next operands are in flight.
+template <int NT, int KS, int FBASE, int NF, int SG = (NT >= 8 ? 1 : (NT >= 4 ? 2 : (NT >= 2 ? 4 : 8))), int W = kWaves>
+__device__ __forceinline__ void mlp_layer(const WStream& w, const float* act, f32x16 (&acc)[NT]) {
+  constexpr int NG = (KS + SG - 1) / SG;
+  float a[2][SG][NT], b[2][SG];
+  auto load = [&](int g, int buf) {
+#pragma unroll
+    for (int d = 0; d < SG; ++d) {
+      const int s = g * SG + d;
+      if (s < KS) {
+        b[buf][d] = act[s * 64];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int f = FBASE + s * NT + t;            // compile-time after unrolling
+          if (f > 0 && f % kChunk == 0) ws_advance<NF, W>(w, f / kChunk);
+          a[buf][d][t] = w.ring[(f % (2 * kChunk)) * 64 + w.lane];
+        }
+      }
+    }
+  };
+  auto comp = [&](int g, int buf) {
+#pragma unroll
+    for (int d = 0; d < SG; ++d) {
+      if (g * SG + d < KS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][d][t], b[buf][d], acc[t], 0, 0, 0);
+      }
+    }
+  };
+  load(0, 0);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) load(g + 1, (g + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    comp(g, g & 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Park NT accumulator tiles as the next layer's activation steps [base, base + 16 NT).
+template <int NT, bool RELU>
+__device__ __forceinline__ void park(const f32x16 (&acc)[NT], float* act, int base) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = acc[t][r];
+      act[(base + t * 16 + r) * 64] = RELU ? fmaxf(v, 0.0f) : v;
+    }
+}
+
+__device__ __forceinline__ float softplus(float x) {
+  // jax.nn.softplus = logaddexp(x, 0) = max(x, 0) + log1p(exp(-|x|))
+  return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ void contract3(float& x, float& y, float& z, float radius) {
+  x = x / radius; y = y / radius; z = z / radius;
+  float mag = x * x + y * y + z * z;
+  mag = fmaxf(1.0f, mag);
+  const float scale = (2.0f * sqrtf(mag) - 1.0f) / mag;
+  x = scale * x; y = scale * y; z = scale * z;
+}
+
+// nan_to_num(-l2_normalize(g)) (ref_utils.py:45-72, geometry.py:460,471)
+__device__ __forceinline__ void neg_normalize(float& x, float& y, float& z) {
+  const float dsq = x * x + y * y + z * z;
+  const float inv = sqrtf(fmaxf(RC_TINY, dsq));
+  float nx = -(x / inv), ny = -(y / inv), nz = -(z / inv);
+  if (dsq < RC_TINY) { nx = 0.0f; ny = 0.0f; nz = 0.0f; }
+  auto fix = [](float v) {
+    if (v != v) return 0.0f;
+    return fminf(fmaxf(v, -RC_FMAX), RC_FMAX);
+  };
+  x = fix(nx); y = fix(ny); z = fix(nz);
+}
+
+
+// (l, m) of IDE term i for deg_view = 5: l in {1,2,4,8,16}, m = 0..l (ref_utils.py:105-115)
+__host__ __device__ constexpr int ide_l(int i) { return i < 2 ? 1 : (i < 5 ? 2 : (i < 10 ? 4 : (i < 19 ? 8 : 16))); }
+__host__ __device__ constexpr int ide_m(int i) { return i < 2 ? i : (i < 5 ? i - 2 : (i < 10 ? i - 5 : (i < 19 ? i - 10 : i - 19))); }
+
+
+// activation slice of the shader (steps): [0,64) bottleneck | [64,100) IDE | 100 bias(1|0) | 101 (dot|1)
+constexpr int kShActSteps = 102;
+constexpr int kStepBias = 100;
+constexpr int kStepDot = 101;
+
+// fragment offsets of the shader's layers inside its weight stream (host: rc_api.hip, same order)
+struct ShaderFrags {
+  static constexpr int F_H = 0, F_S0 = F_H + 49 * 5, F_I0 = F_S0 + 101 * 8, F_I1 = F_I0 + 65 * 2, F_IO = F_I1 + 33 * 2,
+                       F_S1 = F_IO + 33, F_S2 = F_S1 + 65 * 4, F_SB = F_S2 + 65 * 4, F_SO = F_SB + 64 * 4, COUNT = F_SO + 65;
+};
+
+struct ShaderConsts { float roughness_bias, irradiance_bias, ambient_bias, rgb_max, slf_ambient_bias; };
+struct ShadeOut { float rgb[3], ad[3], idf[3], is[3], tint[3]; };
+
+// The cache shader on one 32-point tile.  Expects act steps [0,49) = [hidden density feature (32,
+// accumulator order) | appearance features (16 natural pairs) | bias]; (nx,ny,nz) the shading normal
+// and (vx,vy,vz) the view direction of this lane's point.  F0 = offset of the shader's fragments in
+// the kernel's weight stream of NF fragments.
+template <int F0, int NF>
+__device__ __forceinline__ ShadeOut shader_tile(const WStream& ws, float* act, int lane, int h, float nx, float ny, float nz,
+                                                float vx, float vy, float vz, const RcIdeTable* tb, const ShaderConsts& k) {
+  // ---- heads: bottleneck (4 tiles, linear) + small heads tile
+  float rough, tint[3], ad[3], idf[3];
+  {
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) acc[t] = zero16();
+    mlp_layer<5, 49, F0 + ShaderFrags::F_H, NF>(ws, act, acc);
+    // heads tile, by accumulator register (same on both half-waves): 0 roughness, 1-3 tint,
+    // 4-6 ambient irradiance, 7-9 irradiance
+    rough = softplus(acc[4][0] + k.roughness_bias);                       // nerf.py:633-634
+    tint[0] = sigmoidf(acc[4][1]); tint[1] = sigmoidf(acc[4][2]); tint[2] = sigmoidf(acc[4][3]);   // :976
+    const float ar[3] = {acc[4][4], acc[4][5], acc[4][6]};
+    const float ir[3] = {acc[4][7], acc[4][8], acc[4][9]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      ad[c] = fminf(fmaxf(softplus(ar[c] + k.ambient_bias), 0.0f), k.rgb_max);      // nerf.py:965-969
+      idf[c] = fminf(fmaxf(softplus(ir[c] + k.irradiance_bias), 0.0f), k.rgb_max);  // nerf.py:1008-1012
+    }
+    f32x16 bt[4] = {acc[0], acc[1], acc[2], acc[3]};
+    park<4, false>(bt, act, 0);
+  }
+  // ---- normals, n.(-v), reflection direction, IDE
+  {
+    const float dotp = nx * (-vx) + ny * (-vy) + nz * (-vz);        // nerf.py:474
+    // reflect(-v, n) = 2 (n . -v) n - (-v)  (ref_utils.py:25-42)
+    const float rx = 2.0f * dotp * nx - (-vx), ry = 2.0f * dotp * ny - (-vy), rz = 2.0f * dotp * nz - (-vz);
+    act[kStepBias * 64] = h == 0 ? 1.0f : 0.0f;
+    act[kStepDot * 64] = h == 0 ? dotp : 1.0f;
+    // IDE (ref_utils.py:155-190): low half-wave keeps real parts, high half-wave imaginary parts.
+    float zp[RC_IDE_ZPOW];
+    zp[0] = 1.0f;
+#pragma unroll
+    for (int k = 1; k < RC_IDE_ZPOW; ++k) zp[k] = zp[k - 1] * rz;
+    float cpw[RC_IDE_ZPOW];   // Re or Im of (x + i y)^m for this half-wave
+    {
+      float cre = 1.0f, cim = 0.0f;
+      cpw[0] = h == 0 ? cre : cim;
+#pragma unroll
+      for (int m = 1; m < RC_IDE_ZPOW; ++m) {
+        const float nre = cre * rx - cim * ry;
+        const float nim = cre * ry + cim * rx;
+        cre = nre; cim = nim;
+        cpw[m] = h == 0 ? cre : cim;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RC_IDE_TERMS; ++i) {
+      const int l = ide_l(i), m = ide_m(i);
+      float poly = 0.0f;
+#pragma unroll
+      for (int k = 0; k < RC_IDE_ZPOW; ++k) {
+        // structurally non-zero coefficients only: k <= l - m and (l - m - k) even
+        if (k <= l - m && ((l - m - k) & 1) == 0) poly = poly + zp[k] * tb->coef[i][k];
+      }
+      const float att = expf(-(0.5f * (float)(l * (l + 1))) * rough);
+      act[(64 + i) * 64] = (cpw[m] * poly) * att;
+    }
+  }
+  // ---- SLF layer_0 (tiles 0-3) + input part of layer_bottleneck (tiles 4-7): one pass over
+  //      [bottleneck | IDE | bias]; results stay in registers while the IBRDF chain runs.
+  f32x16 s0[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) s0[t] = zero16();
+  mlp_layer<8, 101, F0 + ShaderFrags::F_S0, NF>(ws, act, s0);
+  // ---- integrated BRDF: (bottleneck, n.v) 129 -> 64 -> 64 -> 1 (nerf.py:461-482)
+  float ibrdf;
+  {
+    f32x16 ib[2];
+    ib[0] = zero16(); ib[1] = zero16();
+    mlp_layer<2, 64, F0 + ShaderFrags::F_I0, NF>(ws, act, ib);
+    mlp_layer<2, 1, F0 + ShaderFrags::F_I0 + 128, NF>(ws, act + kStepDot * 64, ib);   // (n.v | bias) step
+    // IDE is dead now: steps [64, 97) are scratch for the IBRDF tail
+    park<2, true>(ib, act, 64);
+    act[(64 + 32) * 64] = h == 0 ? 1.0f : 0.0f;
+    ib[0] = zero16(); ib[1] = zero16();
+    mlp_layer<2, 33, F0 + ShaderFrags::F_I1, NF>(ws, act + 64 * 64, ib);
+    park<2, true>(ib, act, 64);
+    f32x16 o[1];
+    o[0] = zero16();
+    mlp_layer<1, 33, F0 + ShaderFrags::F_IO, NF>(ws, act + 64 * 64, o);
+    ibrdf = sigmoidf(o[0][0] + 1.0986123f);     // + log(3), nerf.py:481
+  }
+  // ---- SLF trunk: layer_1, layer_2, layer_bottleneck (x part accumulates onto the input part)
+  float amb[3];
+  {
+    f32x16 acc[4] = {s0[0], s0[1], s0[2], s0[3]};
+    f32x16 skip[4] = {s0[4], s0[5], s0[6], s0[7]};
+    park<4, true>(acc, act, 0);
+    act[64 * 64] = h == 0 ? 1.0f : 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = zero16();
+    mlp_layer<4, 65, F0 + ShaderFrags::F_S1, NF>(ws, act, acc);
+    park<4, true>(acc, act, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = zero16();
+    mlp_layer<4, 65, F0 + ShaderFrags::F_S2, NF>(ws, act, acc);
+    park<4, true>(acc, act, 0);
+    mlp_layer<4, 64, F0 + ShaderFrags::F_SB, NF>(ws, act, skip);
+    park<4, true>(skip, act, 0);
+    f32x16 o[1];
+    o[0] = zero16();
+    mlp_layer<1, 65, F0 + ShaderFrags::F_SO, NF>(ws, act, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) amb[c] = fmaxf(softplus(o[0][c] + k.slf_ambient_bias), 0.0f);   // slf.py:1053-1059
+  }
+  ShadeOut o;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    // nerf.py:1034-1053; ambient_specular is an exact 0 (ref_acc == 1)
+    const float is = fminf(fmaxf(tint[c] * ibrdf * (amb[c] * 1.0f), 0.0f), k.rgb_max);
+    const float ambient = ad[c] + 0.0f;
+    const float indirect = idf[c] + is;
+    o.rgb[c] = ambient + indirect; o.ad[c] = ad[c]; o.idf[c] = idf[c]; o.is[c] = is; o.tint[c] = tint[c];
+  }
+  return o;
+}
+
+}  // namespace rcdev

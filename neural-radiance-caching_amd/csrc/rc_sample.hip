@@ -11,139 +11,11 @@
 //   Model.maybe_resample                                                 internal/models.py:193-292
 //   VolumeIntegrator / render.volumetric_rendering / weighted_percentile internal/integration.py:112-289,
 //                                                                        internal/render.py:172-247, stepfun.py:306-314
-#include "rc_internal.h"
+#include "rc_dev_sample.h"
+
+using namespace rcdev;
 
 namespace {
-
-constexpr int kWavesPerBlock = 4;
-constexpr int kMaxBins = 64;          // P, S <= 64
-constexpr int kSlots = kMaxBins + 1;  // fence posts
-
-__device__ __forceinline__ float wave_scan_incl(float v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float t = __shfl_up(v, d, 64);
-    if (lane >= d) v = v + t;
-  }
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = v + __shfl_xor(v, d, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
-  return v;
-}
-
-__device__ __forceinline__ float safe_log(float x) { return logf(fminf(fmaxf(x, RC_TINY), RC_FMAX)); }
-
-// math.power_ladder for finite p not in {0,1} (math.py:295-316)
-__device__ __forceinline__ float power_ladder(float x, float p, float premult) {
-  x = x * premult;
-  const float xp = fabsf(x);
-  const float xs = xp / fmaxf(RC_TINY, fabsf(p - 1.0f));
-  float y = fabsf(p - 1.0f) / p * (powf(xs + 1.0f, p) - 1.0f);
-  y = fminf(fmaxf(y, -RC_FMAX), RC_FMAX);
-  return x < 0.0f ? -y : y;
-}
-// math.inv_power_ladder (math.py:319-341); y_max = minus_eps((p-1)/p) for p < 0.
-__device__ __forceinline__ float inv_power_ladder(float y, float p, float premult, float y_max) {
-  float yp = fabsf(y);
-  if (p < 0.0f) yp = fminf(fmaxf(yp, -y_max), y_max);
-  const float pm1 = fabsf(p - 1.0f);
-  float x = pm1 * (powf((p / pm1) * yp + 1.0f, 1.0f / p) - 1.0f);
-  x = y < 0.0f ? -x : x;
-  return x / premult;
-}
-
-// Alpha-compositing weights of one ray; lane i < S owns interval i.  Returns w, and (by ref) dd.
-__device__ __forceinline__ float alpha_weight(float density, float t0, float t1, float dnorm, bool active, int lane) {
-  // render.py:143-168: delta = (t1-t0)*||d||; dd = density*|delta|; alpha = 1-exp(-dd); T = exp(-excl cumsum)
-  const float dd = active ? density * fabsf((t1 - t0) * dnorm) : 0.0f;
-  const float incl = wave_scan_incl(dd, lane);
-  float excl = __shfl_up(incl, 1, 64);
-  if (lane == 0) excl = 0.0f;
-  const float alpha = 1.0f - expf(-dd);
-  const float trans = expf(-excl);
-  return active ? alpha * trans : 0.0f;
-}
-
-// Number of entries of s[0..m-1] (sorted ascending) that are <= x  (searchsorted side='right').
-__device__ __forceinline__ int upper_bound(const float* s, int m, float x) {
-  int lo = 0, hi = m;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (s[mid] <= x) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
-
-struct USpec { float start, stop, max_jitter; };
-
-// stepfun.sample_intervals on one wave.  s_t/s_cw: LDS [P+1]; writes sorted samples to s_out[0..S].
-// w_logits: lane p < P holds the logit of bin p.
-__device__ __forceinline__ void sample_intervals_wave(float logit, int P, int S, USpec us, bool has_jitter,
-                                                      float jitter, const float* s_t, float* s_cw, float* s_c,
-                                                      float* s_v, float* s_out, int lane) {
-  // softmax (jax.nn.softmax) + integrate_weights (stepfun.py:125-144)
-  const bool binact = lane < P;
-  const float m = wave_max(binact ? logit : -INFINITY);
-  const float e = binact ? expf(logit - m) : 0.0f;
-  const float ssum = wave_sum(e);
-  const float wn = e / ssum;
-  const float incl = wave_scan_incl(wn, lane);
-  if (lane == 0) s_cw[0] = 0.0f;
-  if (lane < P - 1) s_cw[lane + 1] = fminf(1.0f, incl);
-  if (lane == 0) s_cw[P] = 1.0f;
-  __syncthreads();
-  // u (stepfun.py:186-202); linspace = start*(1-step) + stop*step, last == stop
-  if (lane < S) {
-    float u;
-    if (lane == S - 1) {
-      u = us.stop;
-    } else {
-      const float step = (float)lane / (float)(S - 1);
-      u = us.start * (1.0f - step) + us.stop * step;
-    }
-    if (has_jitter) u = u + jitter * us.max_jitter;
-    // sorted_interp (math.py:448-457)
-    const int idx = upper_bound(s_cw, P + 1, u);
-    const int i1 = min(idx, P), i0 = max(idx - 1, 0);
-    const float c0 = s_cw[i0], c1 = s_cw[i1], t0 = s_t[i0], t1 = s_t[i1];
-    const float off = fminf(fmaxf((u - c0) / fmaxf(RC_EPS * RC_EPS, c1 - c0), 0.0f), 1.0f);
-    s_c[lane] = t0 + off * (t1 - t0);
-  }
-  __syncthreads();
-  // midpoints + reflected end posts, clip to [0,1] (stepfun.py:239-248)
-  for (int e2 = lane; e2 <= S; e2 += 64) {
-    float v;
-    if (e2 == 0) {
-      const float mid0 = (s_c[1] + s_c[0]) / 2.0f;
-      v = 2.0f * s_c[0] - mid0;
-    } else if (e2 == S) {
-      const float midl = (s_c[S - 1] + s_c[S - 2]) / 2.0f;
-      v = 2.0f * s_c[S - 1] - midl;
-    } else {
-      v = (s_c[e2] + s_c[e2 - 1]) / 2.0f;
-    }
-    s_v[e2] = fminf(fmaxf(v, 0.0f), 1.0f);
-  }
-  __syncthreads();
-  // jnp.sort: exact rank sort (the input is almost sorted; ties broken by index)
-  for (int e2 = lane; e2 <= S; e2 += 64) {
-    const float v = s_v[e2];
-    int rank = 0;
-    for (int k = 0; k <= S; ++k) {
-      const float o = s_v[k];
-      rank += (o < v) || (o == v && k < e2);
-    }
-    s_out[rank] = v;
-  }
-  __syncthreads();
-}
 
 __global__ __launch_bounds__(kWavesPerBlock * 64) void k_sample_level(RcSampleArgs a, USpec us, float y_max) {
   __shared__ float lds[kWavesPerBlock][5][kSlots + 3];
@@ -290,21 +162,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_resample(RcResampleArgs
 // ---------------------------------------------------------------------------------------------
 // Volume compositing
 // ---------------------------------------------------------------------------------------------
-// jnp.interp(x, xp, fp) on LDS arrays of length m (stepfun.weighted_percentile).
-__device__ __forceinline__ float interp1(float x, const float* xp, const float* fp, int m) {
-  int i = upper_bound(xp, m, x);
-  i = min(max(i, 1), m - 1);
-  const float df = fp[i] - fp[i - 1];
-  const float dxx = xp[i] - xp[i - 1];
-  const float delta = x - xp[i - 1];
-  const float epsilon = 1.4210855e-14f;   // np.spacing(np.finfo(np.float32).eps)
-  const bool dx0 = fabsf(dxx) <= epsilon;
-  float f = dx0 ? fp[i - 1] : fp[i - 1] + (delta / (dx0 ? 1.0f : dxx)) * df;
-  if (x < xp[0]) f = fp[0];
-  if (x > xp[m - 1]) f = fp[m - 1];
-  return f;
-}
-
 __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeArgs a) {
   __shared__ float lds[kWavesPerBlock][2][kSlots + 3];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -423,24 +280,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
       if (a.out.ptr[id]) a.out.ptr[id][ray] = v;
     }
   }
-}
-
-USpec make_uspec(int S, bool has_jitter) {
-  // stepfun.py:186-202: Python-float (double) arithmetic rounded to float32 on use.
-  const double eps = (double)RC_EPS;
-  USpec u;
-  if (!has_jitter) {
-    const double pad = 1.0 / (2.0 * S);
-    u.start = (float)pad;
-    u.stop = (float)(1.0 - pad - eps);
-    u.max_jitter = 0.0f;
-  } else {
-    const double u_max = eps + (1.0 - eps) / S;
-    u.start = 0.0f;
-    u.stop = (float)(1.0 - u_max);
-    u.max_jitter = (float)((1.0 - u_max) / (S - 1) - eps);
-  }
-  return u;
 }
 
 }  // namespace
