@@ -31,6 +31,13 @@ RAYS_PER_BATCH = 1024
 GRID_BYTES = {"grid0": 64 * 192, "grid1": 64 * 224, "grid2": 32 * 1024, "grid_app": 32 * 1024}   # per ray
 SHADER_FLOP_PER_SAMPLE = 253824          # output-relevant (heads + IBRDF + SurfaceLightField MLP)
 SHADED_SAMPLES = 32
+# density MLPs (geometry.py:123-153, 2 x 64 + output heads) per sample of each proposal level, and the
+# backward pass of the last one for the analytic normals (geometry.py:421-460)
+DENSITY_FLOP_PER_SAMPLE = (2 * (6 * 64 + 64 * 64 + 64), 2 * (7 * 64 + 64 * 64 + 64), 2 * (32 * 64 + 64 * 64 + 4 * 64))
+NORMALS_BWD_FLOP_PER_SAMPLE = 2 * (64 + 64 * 64 + 64 * 32)
+SAMPLES = (64, 64, 32)
+FUSED_FLOP_PER_RAY = (sum(s * f for s, f in zip(SAMPLES, DENSITY_FLOP_PER_SAMPLE))
+                      + SHADED_SAMPLES * (SHADER_FLOP_PER_SAMPLE + NORMALS_BWD_FLOP_PER_SAMPLE))
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
 
@@ -69,7 +76,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph-mode", type=int, default=2, help="0 eager, 1 lazy hipGraph, 2 hipGraph at once")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--plan", choices=("fused", "staged"), default="fused",
+                    help="fused: one launch per batch (rc_set_fused 1, default); staged: one launch per stage")
+    ap.add_argument("--streams", type=int, default=1,
                     help="independent batches in flight: step i is enqueued on HIP stream i %% streams")
     ap.add_argument("--profile-mode", type=int, default=2,
                     help="events in the timed region: 0 none, 1 every stage, 2 dominant kernel only")
@@ -102,6 +111,8 @@ def main():
     rc = rc_ext.RadianceCache(cfg, local_rank)
     rc.load_weights(weights)
     rc.set_graph_mode(args.graph_mode)
+    fused = args.plan == "fused"
+    rc.set_fused(fused)
     rays_np = nrc_amd.synthetic_rays(RAYS_PER_BATCH, seed=20200823 + rank)
     rays = {k: torch.from_numpy(np.asarray(v)).to(dev).contiguous() for k, v in rays_np.hot_fields().items()}
     rays["near"] = rays["near"].reshape(-1)
@@ -150,6 +161,8 @@ def main():
         dist.all_gather(list(gathered.chunk(world)), pix)
     sh_ms = rc.stage_times_ms()["shader"] if args.profile_mode else float("nan")
     # separate pass: every stage bracketed by events (not part of `value`)
+    rc.set_fused(False)
+    rc.render_rays(rays, None, out=out)
     rc.set_profiling(1)
     for _ in range(16):
         rc.render_rays(rays, None, out=out)      # single stream: undisturbed per-stage times
@@ -162,7 +175,7 @@ def main():
 
     rays_total = RAYS_PER_BATCH * world * args.steps
     value = rays_total / elapsed
-    flops = SHADER_FLOP_PER_SAMPLE * SHADED_SAMPLES * RAYS_PER_BATCH
+    flops = (FUSED_FLOP_PER_RAY if fused else SHADER_FLOP_PER_SAMPLE * SHADED_SAMPLES) * RAYS_PER_BATCH
     achieved_tf = flops / (sh_ms * 1e-3) / 1e12
     grid_ms = sum(stage[k] for k in GRID_BYTES)
     grid_bytes = sum(GRID_BYTES.values()) * RAYS_PER_BATCH
@@ -176,8 +189,9 @@ def main():
                                "synthetic rays + synthetic weights (configs[1])",
                    "rays_per_batch_per_gpu": RAYS_PER_BATCH, "parallelism": f"ray-sharded x{world}",
                    "launch": "eager" if (args.profile_mode or args.graph_mode == 0) else "hipGraph",
-                   "batches_in_flight": nstr},
-        "roofline": {"kernel": "k_cache_shader", "bound": "mfma", "achieved": achieved_tf,
+                   "batches_in_flight": nstr,
+                   "kernel_plan": "fused: 1 launch per batch, 1 wavefront per ray" if fused else "staged: 13 launches per batch"},
+        "roofline": {"kernel": "k_cache_fused" if fused else "k_cache_shader", "bound": "mfma", "achieved": achieved_tf,
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
                      # HBM-side bytes per launch from the rocprofv3 PMC passes kept under profiles/
                      # (FETCH_SIZE 8933.5 KiB uncorrected + WRITE_SIZE 1920 KiB); not re-measured here
@@ -187,7 +201,7 @@ def main():
         "hashgrid": {"kernels": "k_hashgrid_fwd x4 (grid0, grid1, grid2, grid_app)", "bound": "hbm",
                      "achieved": grid_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": grid_gbs / PEAK_HBM_GBS,
                      "sum_launch_ms": grid_ms, "algorithmic_bytes_per_batch": grid_bytes},
-        "stage_ms_separate_pass": stage,
+        "stage_ms_separate_pass_staged_plan": stage,
     }
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline(cfg, weights, RAYS_PER_BATCH)

@@ -249,6 +249,12 @@ int rc_set_profiling(rc_handle* h, int32_t mode);
  * an identical call (same sizes and pointers) is seen and replay it afterwards (default),
  * 2 = capture on first sight. */
 int rc_set_graph_mode(rc_handle* h, int32_t mode);
+/* Kernel plan of the plain cache pass (pass_mask == RC_PASS_CACHE): 1 (default) = one fused launch per
+ * batch, one wavefront per ray, all intermediates on chip (no workspace: rc_workspace_ptr then has
+ * nothing to show); 0 = one launch per stage (the plan of every other pass mask), which materialises
+ * sdist/tdist/means/features/density/weights per level in the workspace.  Both plans evaluate the same
+ * arithmetic (internal/models.py:1237-1386 / sampling.py:155-353 / nerf.py:426-693). */
+int rc_set_fused(rc_handle* h, int32_t mode);
 int rc_stage_count(void);
 const char* rc_stage_name(int32_t stage);
 int rc_stage_times_ms(rc_handle* h, float* out_ms, int32_t n);

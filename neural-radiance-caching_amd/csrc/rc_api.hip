@@ -95,6 +95,9 @@ struct rc_handle {
   bool ev_used[kEvSlots]{};
   bool ev_created = false;
   int64_t prof_calls = 0;
+  // fused per-ray kernel for the plain cache pass (fused_mode: 0 never, 1 whenever eligible)
+  int fused_mode = 1;
+  bool fused_ok = false;
   // hipGraph replay of the launch sequence (graph_mode: 0 off, 1 capture when a call repeats, 2 always)
   int graph_mode = 1;
   hipStream_t cap_stream = nullptr;
@@ -314,6 +317,7 @@ const HostLayer* need(rc_handle* h, const std::string& path, std::string& missin
 int repack(rc_handle* h) {
   std::string missing;
   const rc_config& c = h->cfg;
+  std::vector<float> fused_parts[4];
   // all grids of the cache path must be loaded
   for (int g = 0; g < 4; ++g)
     for (size_t l = 0; l < h->grids[g].sizes.size(); ++l)
@@ -350,6 +354,7 @@ int repack(rc_handle* h) {
       append(stream, pack(sb, {tile_full(&w1t, 0, 0, false), tile_full(&w1t, 1, 0, false)}));
       append(stream, pack(sb, {tile_full(&w0t, 0, 0, false)}));
     }
+    if (l < 3) fused_parts[l] = stream;
     int rc = upload(h, "dens_" + std::to_string(l), pad_stream(stream));
     if (rc) return rc;
   }
@@ -398,8 +403,39 @@ int repack(rc_handle* h) {
     append(stream, pack(sb, {tile_full(lb, 0, 0, false), tile_full(lb, 1, 0, false), tile_full(lb, 2, 0, false),
                              tile_full(lb, 3, 0, false)}));
     append(stream, pack(s, {tile_by_reg({Col{la, 0}, Col{la, 1}, Col{la, 2}})}));
+    fused_parts[3] = stream;
     int rc = upload(h, "shader", pad_stream(stream));
     if (rc) return rc;
+  }
+  {
+    // fused per-ray kernel (rc_fused.hip): one stream [density MLP 0 | 1 | 2 | shader]; compiled for the
+    // hotdog layout only (3 levels of 64/64/32 samples, 6/7/32 density features, 32 appearance features)
+    int off[4];
+    const int nf = rc_fused_stream_offsets(&off[0], &off[1], &off[2], &off[3]);
+    bool ok = c.num_levels == 3 && c.num_samples[0] == 64 && c.num_samples[1] == 64 && c.num_samples[2] == 32;
+    const int want_lv[4] = {6, 7, 8, 8}, want_f[4] = {1, 1, 4, 4};
+    for (int g = 0; g < 4 && ok; ++g)
+      ok = h->grids[g].dev.num_levels == want_lv[g] && h->grids[g].dev.num_features == want_f[g];
+    // the two half-waves of the last level look up the density / appearance grid with shared level geometry
+    ok = ok && h->grids[2].dev.bbox == h->grids[3].dev.bbox && h->grids[2].dev.precondition == h->grids[3].dev.precondition;
+    for (int l = 0; l < 8 && ok; ++l) {
+      const RcGridLevel &A = h->grids[2].dev.lvl[l], &B = h->grids[3].dev.lvl[l];
+      ok = A.dense == B.dense && A.size == B.size && A.mask == B.mask && A.entries == B.entries;
+    }
+    for (int g = 0; g < 4 && ok; ++g)        // hashed levels: power-of-two tables only (index = hash & mask)
+      for (int l = 0; l < h->grids[g].dev.num_levels && ok; ++l)
+        ok = h->grids[g].dev.lvl[l].dense || h->grids[g].dev.lvl[l].mask != 0;
+    std::vector<float> stream;
+    for (int p = 0; p < 4 && ok; ++p) {
+      ok = (int)(stream.size() / 64) == off[p];
+      append(stream, fused_parts[p]);
+    }
+    ok = ok && (int)(stream.size() / 64) == nf;
+    h->fused_ok = ok;
+    if (ok) {
+      int rc = upload(h, "fused", pad_stream(stream));
+      if (rc) return rc;
+    }
   }
   {
     // model-level EnvMap (secondary-ray background); optional until a secondary pass is requested
@@ -701,6 +737,14 @@ int rc_set_profiling(rc_handle* h, int32_t enabled) {
   return RC_OK;
 }
 
+int rc_set_fused(rc_handle* h, int32_t mode) {
+  if (!h) return RC_ERR_INVALID_ARG;
+  if (mode < 0 || mode > 1) return fail(h, RC_ERR_INVALID_ARG, "rc_set_fused: mode must be 0 or 1");
+  if (mode != h->fused_mode) drop_graphs(h);
+  h->fused_mode = mode;
+  return RC_OK;
+}
+
 int rc_set_graph_mode(rc_handle* h, int32_t mode) {
   if (!h) return RC_ERR_INVALID_ARG;
   if (mode < 0 || mode > 2) return fail(h, RC_ERR_INVALID_ARG, "rc_set_graph_mode: mode must be 0, 1 or 2");
@@ -771,7 +815,7 @@ int rc_sample_intervals(rc_handle* h, const float* t, const float* logits, int64
 namespace {
 
 struct RenderArgs {
-  rc_rays rays; rc_randoms rnd; bool have_rnd; int64_t n; uint32_t mask; rc_outputs out; int slot;
+  rc_rays rays; rc_randoms rnd; bool have_rnd; int64_t n; uint32_t mask; rc_outputs out; int slot; bool fused;
 };
 
 // Enqueue the whole launch sequence on `st` (also used under stream capture).
@@ -784,6 +828,24 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
   const bool secondary = (A.mask & RC_PASS_SECONDARY) != 0;
   const bool resample = secondary || (A.mask & RC_PASS_RESAMPLE);
   const int slot = A.slot;
+  if (A.fused) {
+    RcFusedLaunch F{};
+    F.rays = A.rays; F.n = n;
+    for (int l = 0; l < 3; ++l) { F.jitter[l] = rnd ? rnd->jitter[l] : nullptr; F.num_samples[l] = c.num_samples[l]; }
+    for (int g = 0; g < 4; ++g) F.grid[g] = &h->grids[g].dev;
+    F.wstream = h->packs["fused"].p; F.ide_coef = h->ide_table.p;
+    F.anneal = c.anneal; F.padding = c.resample_padding; F.density_bias = c.density_bias;
+    F.contract_radius = c.contract_radius; F.bg = c.bg_intensity;
+    for (int i = 0; i < 3; ++i) F.pct[i] = c.percentiles[i];
+    F.roughness_bias = c.roughness_bias; F.irradiance_bias = c.irradiance_bias; F.ambient_bias = c.ambient_irradiance_bias;
+    F.rgb_max = c.rgb_max; F.slf_ambient_bias = c.slf_ambient_bias;
+    F.out = A.out;
+    // profiling: the single launch is reported as the "shader" stage, every other stage as 0
+    for (int i = 0; i <= ST_SHADER; ++i) stage_mark(h, slot, i, st);
+    rc_launch_fused(F, st);
+    for (int i = ST_SHADER + 1; i <= ST_COUNT; ++i) stage_mark(h, slot, i, st);
+    return;
+  }
   for (int l = 0; l < NL; ++l) {
     const std::string L = std::to_string(l), Lp = std::to_string(l - 1);
     const int S = c.num_samples[l];
@@ -936,8 +998,11 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_random
     ~PrefixGuard() { h->ws_prefix = ""; }
   } guard{h};
   h->ws_prefix = ws_slot == 0 ? "" : "p" + std::to_string(ws_slot) + ":";
-  if (h->ws_count.find(h->ws_prefix + "acc_ws") == h->ws_count.end() || h->ws_count[h->ws_prefix + "acc_ws"] < n) drop_graphs(h);
-  if ((rc = ensure_workspace(h, n))) return rc;
+  const bool fused = h->fused_mode != 0 && h->fused_ok && pass_mask == RC_PASS_CACHE;
+  if (!fused) {   // the fused kernel keeps every intermediate on chip: no workspace
+    if (h->ws_count.find(h->ws_prefix + "acc_ws") == h->ws_count.end() || h->ws_count[h->ws_prefix + "acc_ws"] < n) drop_graphs(h);
+    if ((rc = ensure_workspace(h, n))) return rc;
+  }
   rc_shader_prepare();
 
   RenderArgs A{};
@@ -945,6 +1010,7 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_random
   A.have_rnd = rnd != nullptr;
   if (rnd) A.rnd = *rnd;
   A.n = n; A.mask = pass_mask; A.out = *out;
+  A.fused = fused;
   A.slot = -1;
   if (h->profiling) {
     A.slot = (int)(h->prof_calls++ % kEvSlots);

@@ -16,6 +16,9 @@ template <> struct Vec<4> { float v[4]; };
 template <int F>
 __device__ __forceinline__ Vec<F> load_entry(const float* __restrict__ table, uint32_t idx) {
   Vec<F> r;
+#ifdef RC_GATHER_FAKE
+  idx &= RC_GATHER_FAKE;
+#endif
   if constexpr (F == 4) {
     const float4 q = reinterpret_cast<const float4*>(table)[idx];
     r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w;
@@ -26,6 +29,8 @@ __device__ __forceinline__ Vec<F> load_entry(const float* __restrict__ table, ui
 }
 
 // coord.contract(x / radius)
+#ifndef RC_DEV_CONTRACT3
+#define RC_DEV_CONTRACT3
 __device__ __forceinline__ void contract3(float& x, float& y, float& z, float radius) {
   x = x / radius; y = y / radius; z = z / radius;
   float mag = x * x + y * y + z * z;
@@ -33,65 +38,99 @@ __device__ __forceinline__ void contract3(float& x, float& y, float& z, float ra
   const float scale = (2.0f * sqrtf(mag) - 1.0f) / mag;
   x = scale * x; y = scale * y; z = scale * z;
 }
+#endif
 
 
-// Trilinear lookup of level L at the (already contracted) position (x, y, z).
-// acc[F]: interpolated features (NOT yet scaled by the precondition factor);
-// jacc[3*F] (JAC): d feature / d loc_a for the three location axes in the level's own axis order.
-template <int F, bool JAC>
-__device__ __forceinline__ void grid_level(const RcGridLevel& L, float bbox, float x, float y, float z, float (&acc)[F],
-                                           float (&jacc)[JAC ? 3 * F : 1]) {
-  const float lo = -bbox, hi = bbox;
-  const float N = (float)L.size;
+// Trilinear lookup of level L at the (already contracted) position (x, y, z), in two halves so that a
+// caller can put the fetches of several levels in flight before combining any of them:
+//   grid_fetch   : cell + weights, issues the 8 corner loads (straight-line code: dense and hashed
+//                  addressing are both computed and selected, a zero-padded corner loads entry 0 and is
+//                  masked afterwards)
+//   grid_combine : acc[F] interpolated features (NOT yet scaled by the precondition factor);
+//                  jacc[3*F] (JAC): d feature / d loc_a for the three location axes in the level's own
+//                  axis order.  Corners are combined in the reference's order (b2 fastest).
+template <int F> struct Corners { Vec<F> val[8]; float cw[3]; uint32_t zero_mask; };
+
+// (x01, y01, z01) = unit_box(bbox, contracted position): level independent, computed once per point.
+// `dense`, `size`, `mask`, `entries` must be wave-uniform (one branch per level, both sides straight-line);
+// `table` may differ per lane.  The per-axis terms of the index are computed once per level (two
+// candidates per axis), a corner then costs an xor/add, the address and the load.
+// x01 = (x - bbox_min) / (bbox_max - bbox_min) (grid_utils.py:820, 863)
+__device__ __forceinline__ float unit_box(float bbox, float x) { return (x - (-bbox)) / (bbox - (-bbox)); }
+
+// POW2: the caller guarantees power-of-two hash tables (mask != 0): no modulo path.
+template <int F, bool POW2 = false>
+__device__ __forceinline__ void grid_fetch(const float* __restrict__ table, int size, uint32_t mask, uint32_t entries,
+                                           bool dense, float x01, float y01, float z01, Corners<F>& C) {
+  const float N = (float)size;
   // x01 * grid_size (grid_utils.py:820, 863)
-  const float cx = ((x - lo) / (hi - lo)) * N;
-  const float cy = ((y - lo) / (hi - lo)) * N;
-  const float cz = ((z - lo) / (hi - lo)) * N;
-
-  float loc[3];
-  if (L.dense) {
+  const float cx = x01 * N;
+  const float cy = y01 * N;
+  const float cz = z01 * N;
+  C.zero_mask = 0;
+  if (dense) {
     // trilerp 'grid' branch: flip(coords - 0.5) then +1 for the zero padding (grid_utils.py:711, 390)
-    loc[0] = (cz - 0.5f) + 1.0f; loc[1] = (cy - 0.5f) + 1.0f; loc[2] = (cx - 0.5f) + 1.0f;
-  } else {
-    loc[0] = cx - 0.5f; loc[1] = cy - 0.5f; loc[2] = cz - 0.5f;     // grid_utils.py:61
-  }
-  float fl[3], cw[3], fw[3];
-  int base[3];
+    const float loc[3] = {(cz - 0.5f) + 1.0f, (cy - 0.5f) + 1.0f, (cx - 0.5f) + 1.0f};
+    int base[3];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    fl[a] = floorf(loc[a]);
-    cw[a] = loc[a] - fl[a];
-    fw[a] = 1.0f - cw[a];
-    base[a] = (int)fl[a];
-  }
-
-  // Issue the 8 corner fetches, then combine in the reference's corner order (b2 fastest).
-  Vec<F> val[8];
-  const int Ni = L.size;
+    for (int a = 0; a < 3; ++a) {
+      const float fl = floorf(loc[a]);
+      C.cw[a] = loc[a] - fl;
+      base[a] = (int)fl;
+    }
+    // clamp to the padded volume [0, N+1]; the pad (0 and N+1) holds zeros (grid_utils.py:384-390, 435-438);
+    // data[loc2, loc1, loc0] = grid[x, y, z]: idx = ((k2-1) N + (k1-1)) N + (k0-1)
+    uint32_t term[3][2];
+    bool out[3][2];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const int b0 = (c >> 2) & 1, b1 = (c >> 1) & 1, b2 = c & 1;
-    const int i0 = base[0] + b0, i1 = base[1] + b1, i2 = base[2] + b2;
-    if (L.dense) {
-      // clamp to the padded volume [0, N+1]; the pad (0 and N+1) holds zeros (grid_utils.py:384-390, 435-438)
-      const int k0 = min(max(i0, 0), Ni + 1), k1 = min(max(i1, 0), Ni + 1), k2 = min(max(i2, 0), Ni + 1);
-      const bool inside = (k0 >= 1) & (k0 <= Ni) & (k1 >= 1) & (k1 <= Ni) & (k2 >= 1) & (k2 <= Ni);
-      // data[loc2, loc1, loc0] = grid[x, y, z]
-      const uint32_t idx = ((uint32_t)(k2 - 1) * (uint32_t)Ni + (uint32_t)(k1 - 1)) * (uint32_t)Ni + (uint32_t)(k0 - 1);
-      if (inside) {
-        val[c] = load_entry<F>(L.table, idx);
-      } else {
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int f = 0; f < F; ++f) val[c].v[f] = 0.0f;
+      for (int b = 0; b < 2; ++b) {
+        const int k = min(max(base[a] + b, 0), size + 1);
+        out[a][b] = (k < 1) | (k > size);
+        const uint32_t km = (uint32_t)(k - 1);
+        term[a][b] = a == 0 ? km : (a == 1 ? km * (uint32_t)size : km * (uint32_t)size * (uint32_t)size);
       }
-    } else {
-      // int32 -> uint32 wraparound hash (grid_utils.py:99-111)
-      const uint32_t h = (uint32_t)i0 ^ ((uint32_t)i1 * kPi2) ^ ((uint32_t)i2 * kPi3);
-      const uint32_t idx = L.mask ? (h & L.mask) : (h % L.entries);
-      val[c] = load_entry<F>(L.table, idx);
+    // fetch order: the two corners that differ in b0 (adjacent entries, almost always one cache line) back to back
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      const int c = ((o & 1) << 2) | (o >> 1);
+      const int b0 = (c >> 2) & 1, b1 = (c >> 1) & 1, b2 = c & 1;
+      const bool zero = out[0][b0] | out[1][b1] | out[2][b2];
+      const uint32_t idx = zero ? 0u : term[2][b2] + term[1][b1] + term[0][b0];
+      C.zero_mask |= (zero ? 1u : 0u) << c;
+      C.val[c] = load_entry<F>(table, idx);
+    }
+  } else {
+    const float loc[3] = {cx - 0.5f, cy - 0.5f, cz - 0.5f};     // grid_utils.py:61
+    int base[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float fl = floorf(loc[a]);
+      C.cw[a] = loc[a] - fl;
+      base[a] = (int)fl;
+    }
+    // int32 -> uint32 wraparound hash (grid_utils.py:99-111): x ^ y * pi2 ^ z * pi3
+    const uint32_t hx[2] = {(uint32_t)base[0], (uint32_t)base[0] + 1u};
+    const uint32_t y0 = (uint32_t)base[1] * kPi2, z0 = (uint32_t)base[2] * kPi3;
+    const uint32_t hy[2] = {y0, y0 + kPi2}, hz[2] = {z0, z0 + kPi3};
+    // fetch order: x and x + 1 (index differs in the low bits only: same cache line 7 times out of 8) back to back
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      const int c = ((o & 1) << 2) | (o >> 1);
+      const int b0 = (c >> 2) & 1, b1 = (c >> 1) & 1, b2 = c & 1;
+      const uint32_t hsh = hx[b0] ^ hy[b1] ^ hz[b2];
+      const uint32_t idx = (POW2 || mask) ? (hsh & mask) : (hsh % entries);
+      C.val[c] = load_entry<F>(table, idx);
     }
   }
+}
 
+template <int F, bool JAC>
+__device__ __forceinline__ void grid_combine(const Corners<F>& C, float (&acc)[F], float (&jacc)[JAC ? 3 * F : 1]) {
+  float fw[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) fw[a] = 1.0f - C.cw[a];
 #pragma unroll
   for (int f = 0; f < F; ++f) acc[f] = 0.0f;
   if constexpr (JAC) {
@@ -101,10 +140,14 @@ __device__ __forceinline__ void grid_level(const RcGridLevel& L, float bbox, flo
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int b0 = (c >> 2) & 1, b1 = (c >> 1) & 1, b2 = c & 1;
-    const float w0 = b0 ? cw[0] : fw[0], w1 = b1 ? cw[1] : fw[1], w2 = b2 ? cw[2] : fw[2];
+    const float w0 = b0 ? C.cw[0] : fw[0], w1 = b1 ? C.cw[1] : fw[1], w2 = b2 ? C.cw[2] : fw[2];
     const float w = (w0 * w1) * w2;
+    const bool zero = (C.zero_mask >> c) & 1u;
+    float v[F];
 #pragma unroll
-    for (int f = 0; f < F; ++f) acc[f] = acc[f] + val[c].v[f] * w;
+    for (int f = 0; f < F; ++f) v[f] = zero ? 0.0f : C.val[c].v[f];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = acc[f] + v[f] * w;
     if constexpr (JAC) {
       // d w / d loc_a = +-(product of the two other weights)
       const float d0 = (b0 ? 1.0f : -1.0f) * (w1 * w2);
@@ -112,13 +155,20 @@ __device__ __forceinline__ void grid_level(const RcGridLevel& L, float bbox, flo
       const float d2 = (b2 ? 1.0f : -1.0f) * (w0 * w1);
 #pragma unroll
       for (int f = 0; f < F; ++f) {
-        jacc[0 * F + f] += val[c].v[f] * d0;
-        jacc[1 * F + f] += val[c].v[f] * d1;
-        jacc[2 * F + f] += val[c].v[f] * d2;
+        jacc[0 * F + f] += v[f] * d0;
+        jacc[1 * F + f] += v[f] * d1;
+        jacc[2 * F + f] += v[f] * d2;
       }
     }
   }
+}
 
+template <int F, bool JAC>
+__device__ __forceinline__ void grid_level(const RcGridLevel& L, float bbox, float x, float y, float z, float (&acc)[F],
+                                           float (&jacc)[JAC ? 3 * F : 1]) {
+  Corners<F> C;
+  grid_fetch<F>(L.table, L.size, L.mask, L.entries, L.dense != 0, unit_box(bbox, x), unit_box(bbox, y), unit_box(bbox, z), C);
+  grid_combine<F, JAC>(C, acc, jacc);
 }
 
 }  // namespace rcdev

@@ -117,6 +117,51 @@ __device__ __forceinline__ void mlp_layer(const WStream& w, const float* act, f3
   }
 }
 
+
+// Same as mlp_layer for PT point-tiles per wave (64 points): every A fragment read from the ring feeds
+// PT MFMAs.  Tile p's activation column starts at act + p * tile_stride.
+template <int PT, int NT, int KS, int FBASE, int NF, int SG = (NT * PT >= 8 ? 1 : (NT * PT >= 4 ? 2 : 4)), int W = kWaves>
+__device__ __forceinline__ void mlp_layer_pt(const WStream& w, const float* act, int tile_stride, f32x16 (&acc)[PT][NT]) {
+  constexpr int NG = (KS + SG - 1) / SG;
+  float a[2][SG][NT], b[2][SG][PT];
+  auto load = [&](int g, int buf) {
+#pragma unroll
+    for (int d = 0; d < SG; ++d) {
+      const int s = g * SG + d;
+      if (s < KS) {
+#pragma unroll
+        for (int p = 0; p < PT; ++p) b[buf][d][p] = act[p * tile_stride + s * 64];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int f = FBASE + s * NT + t;
+          if (f > 0 && f % kChunk == 0) ws_advance<NF, W>(w, f / kChunk);
+          a[buf][d][t] = w.ring[(f % (2 * kChunk)) * 64 + w.lane];
+        }
+      }
+    }
+  };
+  auto comp = [&](int g, int buf) {
+#pragma unroll
+    for (int d = 0; d < SG; ++d) {
+      if (g * SG + d < KS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int p = 0; p < PT; ++p)
+            acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][d][t], b[buf][d][p], acc[p][t], 0, 0, 0);
+      }
+    }
+  };
+  load(0, 0);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) load(g + 1, (g + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    comp(g, g & 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // Park NT accumulator tiles as the next layer's activation steps [base, base + 16 NT).
 template <int NT, bool RELU>
 __device__ __forceinline__ void park(const f32x16 (&acc)[NT], float* act, int base) {
@@ -135,6 +180,8 @@ __device__ __forceinline__ float softplus(float x) {
 }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+#ifndef RC_DEV_CONTRACT3
+#define RC_DEV_CONTRACT3
 __device__ __forceinline__ void contract3(float& x, float& y, float& z, float radius) {
   x = x / radius; y = y / radius; z = z / radius;
   float mag = x * x + y * y + z * z;
@@ -142,6 +189,7 @@ __device__ __forceinline__ void contract3(float& x, float& y, float& z, float ra
   const float scale = (2.0f * sqrtf(mag) - 1.0f) / mag;
   x = scale * x; y = scale * y; z = scale * z;
 }
+#endif
 
 // nan_to_num(-l2_normalize(g)) (ref_utils.py:45-72, geometry.py:460,471)
 __device__ __forceinline__ void neg_normalize(float& x, float& y, float& z) {

@@ -34,6 +34,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int d = 32; d >= 1; d >>= 1) v = v + __shfl_xor(v, d, 64);
   return v;
 }
+// N independent wave sums at once: the N butterflies advance level by level, so the cross-lane
+// exchanges of one level are all in flight together (same add order per sum as wave_sum).
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    float t[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) t[k] = __shfl_xor(v[k], d, 64);
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = v[k] + t[k];
+  }
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));

@@ -213,3 +213,19 @@ struct RcMatIntegrateArgs {
   rc_mat_outputs out;
 };
 void rc_launch_material_integrate(const RcMatIntegrateArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// Fused cache forward (rc_fused.hip): one launch per batch of primary rays
+// ---------------------------------------------------------------------------------------------
+struct RcFusedLaunch {
+  rc_rays rays; int64_t n;
+  const float* jitter[3]; int32_t num_samples[3];
+  const RcGridDev* grid[4];            // proposal 0, 1, 2 + appearance
+  const float* wstream;                // [density MLP 0 | 1 | 2 (+ backward) | shader], see rc_fused_stream_offsets
+  const float* ide_coef;
+  float anneal, padding, density_bias, contract_radius, bg; float pct[3];
+  float roughness_bias, irradiance_bias, ambient_bias, rgb_max, slf_ambient_bias;
+  rc_outputs out;
+};
+int rc_fused_stream_offsets(int* l0, int* l1, int* l2, int* sh);   // returns the total fragment count
+void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream);

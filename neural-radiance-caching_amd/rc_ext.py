@@ -98,7 +98,7 @@ class rc_mat_outputs(C.Structure):
 EXPORTS = (
     "rc_create", "rc_destroy", "rc_last_error", "rc_abi_version", "rc_load_weights", "rc_render_rays",
     "rc_hashgrid_lookup", "rc_sample_intervals", "rc_workspace_ptr", "rc_set_profiling", "rc_stage_count",
-    "rc_stage_name", "rc_stage_times_ms", "rc_set_graph_mode", "rc_render_material",
+    "rc_stage_name", "rc_stage_times_ms", "rc_set_graph_mode", "rc_set_fused", "rc_render_material",
 )
 
 _LIB = None
@@ -146,6 +146,8 @@ def load_library():
     lib.rc_set_profiling.restype = C.c_int
     lib.rc_set_graph_mode.argtypes = [C.c_void_p, C.c_int32]
     lib.rc_set_graph_mode.restype = C.c_int
+    lib.rc_set_fused.argtypes = [C.c_void_p, C.c_int32]
+    lib.rc_set_fused.restype = C.c_int
     lib.rc_stage_count.restype = C.c_int
     lib.rc_stage_name.argtypes = [C.c_int32]
     lib.rc_stage_name.restype = C.c_char_p
@@ -415,6 +417,11 @@ class RadianceCache:
     def set_graph_mode(self, mode: int):
         """0 eager launches, 1 capture a hipGraph when a call repeats (default), 2 capture at once."""
         self._check(self.lib.rc_set_graph_mode(self._h, int(mode)))
+
+    def set_fused(self, on: bool):
+        """Plain cache pass: True (default) one fused launch per batch with every intermediate on chip,
+        False one launch per stage (fills the workspace that `workspace()` shows)."""
+        self._check(self.lib.rc_set_fused(self._h, 1 if on else 0))
 
     def stage_times_ms(self) -> Dict[str, float]:
         n = self.lib.rc_stage_count()

@@ -16,6 +16,7 @@ import nrc_amd
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 RGB_TOL = 1e-4
+FUSED_TOL = 0.0     # fused and launch-per-stage plans run the same arithmetic in the same order: bitwise equal
 
 
 @pytest.fixture(scope="module")
@@ -34,12 +35,27 @@ def rc_shell():
     return h
 
 
-def _render(rc, n, jitter_seed=None, seed=20200823, **kw):
+def _render(rc, n, jitter_seed=None, seed=20200823, fused=True, **kw):
+    """The plain cache pass runs as ONE fused launch by default (rc_set_fused); `fused=False` selects the
+    launch-per-stage plan, which leaves every intermediate in the workspace for inspection."""
     rays = nrc_amd.synthetic_rays(n, seed=seed)
     rnd = None if jitter_seed is None else {"jitter": common.jitters(n, seed=jitter_seed)}
-    out = rc.render_rays(rays.hot_fields(), rnd, **kw)
-    torch.cuda.synchronize()
+    rc.set_fused(fused)
+    try:
+        out = rc.render_rays(rays.hot_fields(), rnd, **kw)
+        torch.cuda.synchronize()
+    finally:
+        rc.set_fused(True)
     return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def _staged_matches(rc, out, n, jitter_seed=None, tol=0.0, **kw):
+    """Re-render with the launch-per-stage plan (fills the workspace) and compare with the fused result."""
+    st = _render(rc, n, jitter_seed, fused=False, **kw)
+    for k, v in out.items():
+        d = np.abs(st[k] - v).max() if v.size else 0.0
+        assert d <= tol, (k, d)
+    return st
 
 
 # ---------------------------------------------------------------------------------------------
@@ -133,7 +149,8 @@ def test_cache_render_256_vs_oracle_fp32(rc, jitter_seed):
         assert np.abs(out[k] - r[k][:, 0]).max() <= 5e-4, k
     for k in ("distance_mean", "distance_median", "distance_percentile_5", "distance_percentile_95"):
         assert np.abs(out[k] - r[k]).max() <= 1e-3, k
-    # intermediate stages
+    # intermediate stages (launch-per-stage plan; its outputs equal the fused kernel's)
+    _staged_matches(rc, out, n, jitter_seed, tol=FUSED_TOL)
     for l, S in enumerate((64, 64, 32)):
         assert np.abs(rc.workspace(f"sdist{l}").reshape(n, S + 1) - ref["sampler"][l]["sdist"].numpy()).max() <= 2e-5
         assert np.abs(rc.workspace(f"tdist{l}").reshape(n, S + 1) - ref["sampler"][l]["tdist"].numpy()).max() <= 1e-4
@@ -177,6 +194,14 @@ def test_ragged_batch_sizes(rc, n):
     assert np.abs(out["acc"] - ref["acc"].numpy()).max() <= RGB_TOL
 
 
+@pytest.mark.parametrize("n,jitter_seed", [(1, None), (5, 2), (257, 11), (2048, 4)])
+def test_fused_plan_equals_staged_plan(rc, n, jitter_seed):
+    """Every output of the fused per-ray kernel against the launch-per-stage plan, incl. analytic normals."""
+    out = _render(rc, n, jitter_seed)
+    assert "normals" in out and "distance_median" in out
+    _staged_matches(rc, out, n, jitter_seed, tol=FUSED_TOL)
+
+
 def test_empty_batch_is_a_noop(rc):
     rays = nrc_amd.synthetic_rays(4)
     f = {k: np.asarray(v)[:0] for k, v in rays.hot_fields().items()}
@@ -194,6 +219,7 @@ def test_full_size_batch_properties_1024(rc):
     assert np.abs(rgb - (out["direct_rgb"] + out["indirect_rgb"] + (1 - acc)[:, None])).max() <= 2e-6
     assert np.abs(out["diffuse_rgb"] + out["specular_rgb"] - out["direct_rgb"] - out["indirect_rgb"]).max() <= 2e-6
     assert np.abs(out["indirect_occ"] - acc[:, None]).max() <= 2e-6
+    _staged_matches(rc, out, n, 3, tol=FUSED_TOL)
     for l, S in enumerate((64, 64, 32)):
         sd = rc.workspace(f"sdist{l}").reshape(n, S + 1)
         td = rc.workspace(f"tdist{l}").reshape(n, S + 1)
@@ -378,6 +404,11 @@ def test_analytic_normals(rc):
     out = rc.render_rays(rays.hot_fields(), None, outputs=["normals", "rgb"])
     torch.cuda.synchronize()
     ref = common.oracle_cache(n, want_grad_normals=True)
+    rc.set_fused(False)
+    staged = rc.render_rays(rays.hot_fields(), None, outputs=["normals", "rgb"])
+    torch.cuda.synchronize()
+    rc.set_fused(True)
+    assert torch.equal(staged["normals"], out["normals"]) and torch.equal(staged["rgb"], out["rgb"])
     ng = rc.workspace("normals_grad").reshape(3, n, 32).transpose(1, 2, 0)
     rn = ref["sampler"][2]["normals"].numpy()
     d = np.abs(ng - rn)

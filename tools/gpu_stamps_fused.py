@@ -1,0 +1,34 @@
+"""Diagnostic: per-phase cycle shares of the fused cache kernel (tools/diag/librc_hip.so, make diag)."""
+import ctypes, os, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import numpy as np, torch
+import nrc_amd
+from nrc_amd import rc_ext
+rc_ext.library_path = lambda: os.path.join(R, "tools", "diag", "librc_hip.so")
+cfg = nrc_amd.hotdog_config()
+rc = rc_ext.RadianceCache(cfg, 0); rc.load_weights(nrc_amd.synthetic_weights(cfg))
+rc.set_graph_mode(0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+outs = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+rays = nrc_amd.synthetic_rays(n)
+f = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in rays.hot_fields().items()}
+for _ in range(5): rc.render_rays(f, None, outputs=outs) if outs else rc.render_rays(f, None)
+torch.cuda.synchronize()
+rc.lib.rc_debug_fused_stamps.restype = ctypes.c_void_p
+ptr = rc.lib.rc_debug_fused_stamps()
+buf = torch.empty(n * 16, dtype=torch.int64, device="cuda")
+import ctypes as C
+hip = C.CDLL("libamdhip64.so")
+hip.hipMemcpy(C.c_void_p(buf.data_ptr()), C.c_void_p(ptr), C.c_size_t(n * 16 * 8), 3)
+torch.cuda.synchronize()
+d = buf.cpu().numpy().reshape(n, 16)
+seg = np.diff(d[:, :12], axis=1)
+names = ["begin+resample0", "gather0", "mlp0+w", "resample1", "gather1", "mlp1+w", "resample2", "gather2", "mlp2(+bwd)", "shader", "composite"]
+tot = d[:, 11] - d[:, 0]
+rt = d[:, 15] - d[:, 14]
+ghz = np.median(tot) / (np.median(rt) * 10)
+print("clock GHz", ghz)
+for i, nm in enumerate(names[:11]):
+    print(f"  {nm:12s} median {np.median(seg[:, i]):9.0f} cyc = {np.median(seg[:, i]) / ghz / 1e3:7.2f} us   p95 {np.percentile(seg[:, i], 95) / ghz / 1e3:7.2f} us")
+print("total median us", np.median(tot) / ghz / 1e3, "kernel span us", (d[:, 15].max() - d[:, 14].min()) / 100.0, "start skew us", (d[:, 14].max() - d[:, 14].min()) / 100.0)
+print("gather0 detail us: pos+contract", np.median(d[:, 12] - d[:, 1]) / ghz / 1e3, "issue", np.median(d[:, 13] - d[:, 12]) / ghz / 1e3, "wait+combine", np.median(d[:, 2] - d[:, 13]) / ghz / 1e3)
