@@ -21,14 +21,34 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kMaxBins = 64;          // P, S <= 64
 constexpr int kSlots = kMaxBins + 1;  // fence posts
 
-__device__ __forceinline__ float wave_scan_incl(float v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float t = __shfl_up(v, d, 64);
-    if (lane >= d) v = v + t;
-  }
-  return v;
+// Cross-lane data movement on the VALU (DPP), no LDS round trip.  CTRL: row_shr:n = 0x110 + n,
+// row_bcast:15 = 0x142, row_bcast:31 = 0x143.  Lanes without a source (or masked off) receive `old`.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                               CTRL, ROW_MASK, BANK_MASK, false));
 }
+// Inclusive scan of a wave with an associative op (identity `id`): 3 row shifts of the input, 2 of the
+// partial result (row prefix), then the row totals are passed on with the two row broadcasts.
+template <typename Op>
+__device__ __forceinline__ float wave_scan_op(float x, float id, Op op) {
+  float r = op(x, dpp_mov<0x111>(id, x));
+  r = op(r, dpp_mov<0x112>(id, x));
+  r = op(r, dpp_mov<0x113>(id, x));
+  r = op(r, dpp_mov<0x114, 0xf, 0xe>(id, r));
+  r = op(r, dpp_mov<0x118, 0xf, 0xc>(id, r));
+  r = op(r, dpp_mov<0x142, 0xa, 0xf>(id, r));
+  r = op(r, dpp_mov<0x143, 0xc, 0xf>(id, r));
+  return r;
+}
+__device__ __forceinline__ float lane63(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_scan_incl(float v, int /*lane*/) {
+  return wave_scan_op(v, 0.0f, [](float a, float b) { return a + b; });
+}
+// total of the wave in scan order (lane 63 of the inclusive scan), broadcast
+__device__ __forceinline__ float wave_sum_scan(float v) { return lane63(wave_scan_incl(v, 0)); }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v = v + __shfl_xor(v, d, 64);
@@ -48,9 +68,7 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
   }
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
-  return v;
+  return lane63(wave_scan_op(v, -INFINITY, [](float a, float b) { return fmaxf(a, b); }));
 }
 
 __device__ __forceinline__ float safe_log(float x) { return logf(fminf(fmaxf(x, RC_TINY), RC_FMAX)); }
@@ -79,8 +97,7 @@ __device__ __forceinline__ float alpha_weight(float density, float t0, float t1,
   // render.py:143-168: delta = (t1-t0)*||d||; dd = density*|delta|; alpha = 1-exp(-dd); T = exp(-excl cumsum)
   const float dd = active ? density * fabsf((t1 - t0) * dnorm) : 0.0f;
   const float incl = wave_scan_incl(dd, lane);
-  float excl = __shfl_up(incl, 1, 64);
-  if (lane == 0) excl = 0.0f;
+  float excl = dpp_mov<0x138>(0.0f, incl);      // wave_shr:1, lane 0 keeps 0
   const float alpha = 1.0f - expf(-dd);
   const float trans = expf(-excl);
   return active ? alpha * trans : 0.0f;
@@ -108,7 +125,7 @@ __device__ __forceinline__ void sample_intervals_wave(float logit, int P, int S,
   const bool binact = lane < P;
   const float m = wave_max(binact ? logit : -INFINITY);
   const float e = binact ? expf(logit - m) : 0.0f;
-  const float ssum = wave_sum(e);
+  const float ssum = wave_sum_scan(e);
   const float wn = e / ssum;
   const float incl = wave_scan_incl(wn, lane);
   if (lane == 0) s_cw[0] = 0.0f;
@@ -148,15 +165,25 @@ __device__ __forceinline__ void sample_intervals_wave(float logit, int P, int S,
     s_v[e2] = fminf(fmaxf(v, 0.0f), 1.0f);
   }
   lds_sync<BLOCK_SYNC>();
-  // jnp.sort: exact rank sort (the input is almost sorted; ties broken by index)
-  for (int e2 = lane; e2 <= S; e2 += 64) {
-    const float v = s_v[e2];
-    int rank = 0;
-    for (int k = 0; k <= S; ++k) {
-      const float o = s_v[k];
-      rank += (o < v) || (o == v && k < e2);
+  // jnp.sort: exact rank sort (ties broken by index).  The input is sorted already unless a rounding
+  // step at a bin boundary produced an inversion: a wave that owns its arrays checks and copies.
+  bool need_sort = true;
+  if constexpr (!BLOCK_SYNC) {
+    const bool inv = lane < S && s_v[lane] > s_v[lane + 1];
+    need_sort = __ballot(inv) != 0ull;
+  }
+  if (need_sort) {
+    for (int e2 = lane; e2 <= S; e2 += 64) {
+      const float v = s_v[e2];
+      int rank = 0;
+      for (int k = 0; k <= S; ++k) {
+        const float o = s_v[k];
+        rank += (o < v) || (o == v && k < e2);
+      }
+      s_out[rank] = v;
     }
-    s_out[rank] = v;
+  } else {
+    for (int e2 = lane; e2 <= S; e2 += 64) s_out[e2] = s_v[e2];
   }
   lds_sync<BLOCK_SYNC>();
 }
