@@ -259,6 +259,63 @@ int rc_stage_count(void);
 const char* rc_stage_name(int32_t stage);
 int rc_stage_times_ms(rc_handle* h, float* out_ms, int32_t n);
 
+/* ------------------------------------------------------------------------------------------------
+ * Time-resolved cache (BASELINE configs[4]): TransientNeRFModel.__call__ for primary rays
+ * (internal/models.py:912-985 over BaseNeRFModel.__call__ :657-774) = ProposalVolumeSampler ->
+ * TransientNeRFMLP (internal/nerf.py:561-938, 1656-1797) -> TransientVolumeIntegrator
+ * (internal/integration.py:343-551, internal/render.py:250-507).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct rc_transient_config {
+  int32_t n_bins;                   /* Config.n_bins (700 is the only compiled size)                   */
+  float exposure_time;              /* Config.exposure_time                                             */
+  float tfilter_sigma;              /* Config.tfilter_sigma (0: no temporal filter)                     */
+  float transient_shift;            /* Config.transient_shift                                           */
+  int32_t bin_zero_threshold_light; /* Config.bin_zero_threshold_light                                  */
+  float light_near;                 /* Config.light_near                                                */
+  int32_t light_zero;               /* Config.light_zero                                                */
+  int32_t use_falloff;              /* Config.use_falloff                                               */
+  float indirect_scale;             /* TransientNeRFMLP.indirect_scale                                  */
+  float rgb_max;                    /* TransientNeRFMLP.rgb_max                                         */
+  float albedo_bias;                /* TransientNeRFMLP.albedo_bias (activation softplus)               */
+  float brdf_bias;                  /* BaseNeRFMLP.brdf_bias                                            */
+  float irradiance_bias;            /* TransientNeRFMLP.irradiance_bias                                 */
+  float slf_rgb_bias;               /* TransientSurfaceLightFieldMLP.rgb_bias                           */
+  int32_t use_occlusions;           /* must be 0 this round (shadow rays: RC_ERR_UNSUPPORTED)           */
+  int32_t reserved[9];
+} rc_transient_config;
+
+/* Switches a freshly created handle to the transient model: rc_load_weights then expects the
+ * TransientNeRFMLP inventory (direct_tint_layer, albedo_layer, brdf_layers_*, irradiance_layers_*,
+ * transient_indirect_layer, light_power, SurfaceLightField with lights and 3 n_bins + 1 outputs) and
+ * rc_render_transient becomes available (rc_render_rays / rc_render_material are then refused). */
+int rc_set_transient(rc_handle* h, const rc_transient_config* t);
+
+typedef enum rc_transient_output_id {
+  RC_TOUT_RGB = 0,                 /* [n, n_bins, 3]  transient_direct (filtered) + transient_indirect   */
+  RC_TOUT_TRANSIENT_DIRECT_VIZ,    /* [n, n_bins, 3]                                                     */
+  RC_TOUT_TRANSIENT_INDIRECT_VIZ,  /* [n, n_bins, 3]  (= the reference's final "transient_indirect")     */
+  RC_TOUT_TRANSIENT_INDIRECT_DIFFUSE,   /* [n, n_bins, 3] unshifted composite (integration.py extras)    */
+  RC_TOUT_TRANSIENT_INDIRECT_SPECULAR,  /* [n, n_bins, 3]                                                */
+  RC_TOUT_INTEGRATED_RGB,          /* [n, 3] sum of RGB over bins                                        */
+  RC_TOUT_DIRECT_RGB, RC_TOUT_INDIRECT_RGB,
+  RC_TOUT_DIFFUSE_RGB, RC_TOUT_SPECULAR_RGB, RC_TOUT_ALBEDO_RGB, RC_TOUT_OCC, RC_TOUT_INDIRECT_OCC,
+  RC_TOUT_IRRADIANCE_RGB, RC_TOUT_LIGHT_RADIANCE_RGB, RC_TOUT_N_DOT_L_RGB, RC_TOUT_DIRECT_DIFFUSE_RGB,
+  RC_TOUT_DIRECT_SPECULAR_RGB, RC_TOUT_INDIRECT_DIFFUSE_RGB, RC_TOUT_INDIRECT_SPECULAR_RGB,
+  RC_TOUT_DIRECT_RGB_VIZ,          /* [n, 3] each                                                        */
+  RC_TOUT_ACC, RC_TOUT_DISTANCE_MEAN, RC_TOUT_DISTANCE_MEDIAN, RC_TOUT_DISTANCE_PERCENTILE_5,
+  RC_TOUT_DISTANCE_PERCENTILE_95,  /* [n]                                                                */
+  RC_TOUT_MEANS, RC_TOUT_NORMALS, RC_TOUT_NORMALS_PRED,   /* [n, 3]                                       */
+  RC_TOUT_RAY_DISTS, RC_TOUT_LIGHT_DISTS,                 /* [n]                                          */
+  RC_TOUT_COUNT
+} rc_transient_output_id;
+typedef struct rc_transient_outputs { float* ptr[RC_TOUT_COUNT]; } rc_transient_outputs;   /* NULL = not wanted */
+
+/* rays->lights is required; cam_origins [n,3] is the camera centre of each ray (Rays.cam_origins,
+ * internal/inverse_render/render_utils.py:1733-1740).  Direct-light bins beyond n_bins spill into the
+ * next ray of THIS call's batch exactly as the reference's flattened scatter does (internal/render.py:447-475). */
+int rc_render_transient(rc_handle* h, const rc_rays* rays, const float* cam_origins, int64_t n, const rc_randoms* rnd,
+                        const rc_transient_outputs* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,6 +4,6 @@ benattal/neural-radiance-caching's Model.__call__ / render_image).
 Import as `nrc_amd` (the directory name carries the reference's hyphenated name;
 `nrc_amd.py` at the repository root registers this package under that module name).
 """
-from .config import GridConfig, RenderConfig, hotdog_config  # noqa: F401
-from .rays import Rays, synthetic_rays, synthetic_camera_rays  # noqa: F401
+from .config import GridConfig, RenderConfig, TransientConfig, cornell_transient_config, hotdog_config  # noqa: F401
+from .rays import Rays, synthetic_rays, synthetic_camera_rays, synthetic_transient_rays  # noqa: F401
 from .weights import param_shapes, synthetic_weights  # noqa: F401

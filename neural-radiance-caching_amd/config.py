@@ -54,6 +54,40 @@ class GridConfig:
 
 
 @dataclasses.dataclass(frozen=True)
+class TransientConfig:
+    """Time-resolved cache (TransientNeRFMLP / TransientVolumeIntegrator), cornell values:
+    configs/transient_simulation_ngp_yobo_cornell.gin -> transient_simulation_ngp_yobo.gin ->
+    transient_ngp_yobo.gin -> trainer.gin, internal/configs.py defaults otherwise."""
+
+    n_bins: int = 700                 # cornell.gin:20, configs.py:697
+    exposure_time: float = 0.01       # cornell.gin:21
+    tfilter_sigma: float = 3.0        # configs.py:710 (no impulse response in the simulated sets)
+    transient_shift: float = 0.0      # configs.py:691 (learnable_light=False, configs.py:615)
+    bin_zero_threshold_light: int = 100   # cornell.gin:79
+    light_near: float = 0.7           # cornell.gin:29 (vis_only: Config.near = 0.7, engine/trainer.py:202)
+    light_zero: bool = True           # cornell.gin:30
+    use_falloff: bool = True          # configs.py:621
+    light_power_bias: float = 3.9     # cornell.gin:130 (initial value of the `light_power` parameter)
+    indirect_scale: float = 0.05      # cornell.gin:136
+    rgb_max: float = 100.0            # cornell.gin:26
+    albedo_bias: float = -1.0         # transient_simulation_ngp_yobo.gin:337 (activation softplus :336)
+    brdf_bias: float = -1.09861228867  # nerf.py:128-130
+    irradiance_bias: float = -2.0     # transient_simulation_ngp_yobo.gin:331
+    slf_rgb_bias: float = -2.0        # TransientSurfaceLightFieldMLP.rgb_bias, transient_simulation_ngp_yobo.gin:342
+    deg_lights: int = 2               # nerf.py:196, surface_light_field.py:118
+    deg_brdf: int = 2                 # transient_ngp_yobo.gin:167
+    brdf_width: int = 64              # transient_ngp_yobo.gin:169
+    irradiance_width: int = 64        # transient_ngp_yobo.gin:172-173
+    # occlusions (shadow rays through the cache, weights only): off in the training gin (cornell.gin:39-41),
+    # forced on for every ray by the Trainer in vis_only mode (engine/trainer.py:198-202)
+    use_occlusions: bool = False
+    occ_threshold: float = 0.9        # cornell.gin:167-168 (min == max)
+    shadow_near: float = 0.1          # cornell.gin:172-173 (min == max)
+    shadow_normal_eps_dot_min: float = 0.1   # cornell.gin:176
+    shadow_far: float = 1.0           # Config.secondary_far, cornell.gin:33
+
+
+@dataclasses.dataclass(frozen=True)
 class RenderConfig:
     # --- ProposalVolumeSampler (internal/sampling.py:45-120) -----------------
     # (mlp_idx, grid_idx, num_samples) per round; nerf_ngp_yobo.gin:521-535
@@ -115,6 +149,8 @@ class RenderConfig:
     vmf_scale: float = 20.0
     # --- host chunking (internal/models.py:2409) ---------------------------------
     render_chunk_size: int = 1024     # README quick-start operating point
+    # --- time-resolved cache (None for the steady-state models) ------------------
+    transient: "TransientConfig | None" = None
 
     @property
     def num_levels(self) -> int:
@@ -124,3 +160,20 @@ class RenderConfig:
 def hotdog_config(**overrides) -> RenderConfig:
     """configs/nerf_ngp_yobo_hotdog.gin resolved at render time (train=False)."""
     return dataclasses.replace(RenderConfig(), **overrides)
+
+
+def cornell_transient_config(**overrides) -> RenderConfig:
+    """configs/transient_simulation_ngp_yobo_cornell.gin resolved at render time: the hotdog sampler and
+    grids with contract_radius_5 and HashEncoding.bbox_scaling = 2 (cornell.gin:159-165), the
+    TransientNeRFMLP shader and the TransientVolumeIntegrator.  `use_occlusions=True` selects the
+    vis_only behaviour (engine/trainer.py:198-202)."""
+    t_over = {k: overrides.pop(k) for k in list(overrides) if k in TransientConfig.__dataclass_fields__}
+    g = lambda n, f: GridConfig(max_grid_size=n, num_features=f, bbox=2.0)
+    base = RenderConfig(
+        proposal_grids=(g(512, 1), g(1024, 1), g(2048, 4)),      # transient_ngp_yobo.gin:190-205
+        appearance_grid=g(2048, 4),                              # transient_ngp_yobo.gin:175-180
+        contract_radius=5.0,
+        rgb_max=100.0,
+        transient=dataclasses.replace(TransientConfig(), **t_over),
+    )
+    return dataclasses.replace(base, **overrides)

@@ -95,6 +95,13 @@ struct rc_handle {
   bool ev_used[kEvSlots]{};
   bool ev_created = false;
   int64_t prof_calls = 0;
+  // time-resolved cache (rc_set_transient): TransientNeRFMLP inventory + rc_render_transient
+  bool transient = false;
+  rc_transient_config tcfg{};
+  float light_power = 0.0f;
+  bool have_light_power = false;
+  DevBuf taps;
+  int n_taps = 0;
   // fused per-ray kernel for the plain cache pass (fused_mode: 0 never, 1 whenever eligible)
   int fused_mode = 1;
   bool fused_ok = false;
@@ -160,7 +167,7 @@ void init_grid(GridState& gs, const rc_grid_config& cfg, const std::string& pref
 }
 
 // The dense layers the cache path reads: path -> (in, out).
-std::map<std::string, std::pair<int, int>> dense_inventory(const rc_config& c) {
+std::map<std::string, std::pair<int, int>> dense_inventory(const rc_config& c, const rc_transient_config* tc = nullptr) {
   std::map<std::string, std::pair<int, int>> m;
   const int W = 64, B = 128;
   for (int l = 0; l < c.num_levels; ++l) {
@@ -173,6 +180,32 @@ std::map<std::string, std::pair<int, int>> dense_inventory(const rc_config& c) {
   }
   const std::string sh = "params/Cache/Shader";
   const int feat = W + (int)grid_sizes(c.appearance_grid).size() * c.appearance_grid.num_features;
+  if (tc) {
+    // TransientNeRFMLP + TransientSurfaceLightFieldMLP (nerf.py:232-414, surface_light_field.py:343-403):
+    // pos_enc degree 2 for lights and BRDF dots (15 values), IDE degree 5 (72 values)
+    m[sh + "/bottleneck_layer"] = {feat, B};
+    m[sh + "/roughness_layer"] = {feat, 1};
+    m[sh + "/tint_layer"] = {feat, 3};
+    m[sh + "/direct_tint_layer"] = {feat, 3};
+    m[sh + "/albedo_layer"] = {feat, 3};
+    m[sh + "/integrated_brdf_layers_0"] = {B + 1, 64};
+    m[sh + "/integrated_brdf_layers_1"] = {64, 64};
+    m[sh + "/output_integrated_brdf_layer"] = {64, 1};
+    m[sh + "/brdf_layers_0"] = {B + 15, 64};
+    m[sh + "/brdf_layers_1"] = {64, 64};
+    m[sh + "/output_brdf_layer"] = {64, 1};
+    m[sh + "/irradiance_layers_0"] = {feat + 15, 64};
+    m[sh + "/irradiance_layers_1"] = {64, 64};
+    m[sh + "/transient_indirect_layer"] = {64, 3 * tc->n_bins};
+    const std::string sl = sh + "/SurfaceLightField";
+    const int in = B + 72 + 15;
+    m[sl + "/layer_0"] = {in, 128};
+    m[sl + "/layer_1"] = {128, 128};
+    m[sl + "/layer_2"] = {128, 128};
+    m[sl + "/layer_bottleneck"] = {128 + in, 128};
+    m[sl + "/output_rgba_layer"] = {128, 3 * tc->n_bins + 1};
+    return m;
+  }
   m[sh + "/bottleneck_layer"] = {feat, B};
   m[sh + "/roughness_layer"] = {feat, 1};
   m[sh + "/tint_layer"] = {feat, 3};
@@ -314,6 +347,8 @@ const HostLayer* need(rc_handle* h, const std::string& path, std::string& missin
   return &it->second;
 }
 
+int repack_transient(rc_handle* h);
+
 int repack(rc_handle* h) {
   std::string missing;
   const rc_config& c = h->cfg;
@@ -358,6 +393,7 @@ int repack(rc_handle* h) {
     int rc = upload(h, "dens_" + std::to_string(l), pad_stream(stream));
     if (rc) return rc;
   }
+  if (h->transient) return repack_transient(h);
   const std::string sh = "params/Cache/Shader";
   const HostLayer* bott = need(h, sh + "/bottleneck_layer", missing);
   const HostLayer* rough = need(h, sh + "/roughness_layer", missing);
@@ -546,6 +582,12 @@ int ensure_workspace(rc_handle* h, int64_t n) {
   if ((rc = ws_alloc(h, "inds", n))) return rc;
   if ((rc = ws_alloc(h, "src_idx", n))) return rc;
   if ((rc = ws_alloc(h, "filt_weight", n))) return rc;
+  if (h->transient) {
+    const int64_t tiles = (np + 31) / 32;
+    if ((rc = ws_alloc(h, "t_irr", tiles * 32 * 64))) return rc;
+    if ((rc = ws_alloc(h, "t_slf", tiles * 64 * 64))) return rc;
+    if ((rc = ws_alloc(h, "tshade", (int64_t)RC_TS_COUNT * np))) return rc;
+  }
   if (n > h->ws_rays) h->ws_rays = n;
   return RC_OK;
 }
@@ -663,7 +705,7 @@ int rc_load_weights(rc_handle* h, const rc_tensor_desc* descs, int32_t n) {
   if (!h) return RC_ERR_INVALID_ARG;
   if (!descs && n > 0) return fail(h, RC_ERR_INVALID_ARG, "rc_load_weights: null descs");
   RC_HIP(h, hipSetDevice(h->device));
-  const auto inv = dense_inventory(h->cfg);
+  const auto inv = dense_inventory(h->cfg, h->transient ? &h->tcfg : nullptr);
   for (int i = 0; i < n; ++i) {
     const rc_tensor_desc& d = descs[i];
     if (!d.name || !d.data) return fail(h, RC_ERR_INVALID_ARG, "rc_load_weights: null name/data");
@@ -696,6 +738,13 @@ int rc_load_weights(rc_handle* h, const rc_tensor_desc* descs, int32_t n) {
       if (!handled) return fail(h, RC_ERR_INVALID_ARG, "rc_load_weights: unknown grid level " + name);
     }
     if (handled) continue;
+    if (h->transient && name == "params/Cache/Shader/light_power") {     // nerf.py:400-409
+      if (count != 1) return fail(h, RC_ERR_SHAPE, "rc_load_weights: bad shape for " + name);
+      if (d.on_device) RC_HIP(h, hipMemcpy(&h->light_power, d.data, sizeof(float), hipMemcpyDeviceToHost));
+      else memcpy(&h->light_power, d.data, sizeof(float));
+      h->have_light_power = true;
+      continue;
+    }
     // dense layers
     const size_t slash = name.rfind('/');
     if (slash == std::string::npos) return fail(h, RC_ERR_INVALID_ARG, "rc_load_weights: unknown tensor " + name);
@@ -816,7 +865,10 @@ namespace {
 
 struct RenderArgs {
   rc_rays rays; rc_randoms rnd; bool have_rnd; int64_t n; uint32_t mask; rc_outputs out; int slot; bool fused;
+  const rc_transient_outputs* tout = nullptr; const float* cam_origins = nullptr;
 };
+
+void enqueue_transient_tail(rc_handle* h, const RenderArgs& A, hipStream_t st);
 
 // Enqueue the whole launch sequence on `st` (also used under stream capture).
 void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
@@ -909,6 +961,10 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
   stage_mark(h, slot, ST_GRID_APP, st);
   rc_launch_hashgrid_src(h->grids[3].dev, W(h, "means" + LL), 1, src, np2, nsh, W(h, "app"), 1, nsh,
                          c.contract_radius, nullptr, st);
+  if (A.tout) {
+    enqueue_transient_tail(h, A, st);
+    return;
+  }
   stage_mark(h, slot, ST_SHADER, st);
   {
     RcShaderArgs s{};
@@ -967,6 +1023,7 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_random
   if (n == 0) return RC_OK;
   if (!rays->origins || !rays->directions || !rays->viewdirs || !rays->near || !rays->far)
     return fail(h, RC_ERR_INVALID_ARG, "rc_render_rays: origins/directions/viewdirs/near/far are required");
+  if (h->transient) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_rays: this handle renders the time-resolved cache (rc_render_transient)");
   if (!(pass_mask & RC_PASS_CACHE)) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_rays: pass_mask must include RC_PASS_CACHE");
   const bool secondary = (pass_mask & RC_PASS_SECONDARY) != 0;
   const bool resample = secondary || (pass_mask & RC_PASS_RESAMPLE);
@@ -1071,6 +1128,7 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
                        const rc_material_randoms* mr, int32_t K, const rc_outputs* cache_out,
                        const rc_mat_outputs* mat_out, void* stream_v) {
   if (!h) return RC_ERR_INVALID_ARG;
+  if (h->transient) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_material: this handle renders the time-resolved cache (rc_render_transient)");
   if (!rays || !mr || !cache_out || !mat_out) return fail(h, RC_ERR_INVALID_ARG, "rc_render_material: null argument");
   if (n < 0) return fail(h, RC_ERR_INVALID_ARG, "rc_render_material: negative n_rays");
   if (n == 0) return RC_OK;
@@ -1215,3 +1273,5 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
 }
 
 }  // extern "C"
+
+#include "rc_transient_host.inc"

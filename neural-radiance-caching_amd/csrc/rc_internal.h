@@ -229,3 +229,43 @@ struct RcFusedLaunch {
 };
 int rc_fused_stream_offsets(int* l0, int* l1, int* l2, int* sh);   // returns the total fragment count
 void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream);
+
+
+// ---------------------------------------------------------------------------------------------
+// Time-resolved cache (rc_transient.hip)
+// ---------------------------------------------------------------------------------------------
+// per-sample channels written by k_transient_shader ([RC_TS_COUNT][n], channel-major)
+enum { RC_TS_DD = 0, RC_TS_DS = 3, RC_TS_ALBEDO = 6, RC_TS_TIB = 9, RC_TS_ROUGH = 12, RC_TS_NDOTL = 13, RC_TS_IRRAD = 14,
+       RC_TS_OCC = 15, RC_TS_LDIST = 16, RC_TS_RDIST = 17, RC_TS_CAMDIST = 18, RC_TS_COUNT = 19 };
+
+struct RcTransShaderArgs {
+  int64_t n; int32_t samples_per_ray;
+  const float* hbuf; const float* app; const float* means; const float* normals;   // means / normals: SoA [3][n]
+  const float* origins; const float* viewdirs; const float* lights; const float* cam_origins;   // per ray [.,3]
+  const float* occ;                        // optional per-sample occlusion [n]
+  const float* wstream; const float* ide_coef;
+  float roughness_bias, albedo_bias, brdf_bias, rgb_max, contract_radius;
+  float light_power, light_near; int32_t use_falloff, light_zero;
+  float* irr_feat;                         // [tiles][32 steps][64 lanes]
+  float* slf_feat;                         // [tiles][64 steps][64 lanes]
+  float* tshade;                           // [RC_TS_COUNT][n]
+};
+
+struct RcTransBinsArgs {
+  int64_t n_rays;
+  const float* wstream;                    // per column tile: 65 SLF output fragments | 33 transient_indirect fragments
+  const float* slf_feat; const float* irr_feat; const float* tshade; const float* weights;   // weights [n_rays][32]
+  float exposure, shift, max_dists, irradiance_bias, slf_rgb_bias, indirect_scale, rgb_max, light_near;
+  int32_t bin_zero_threshold_light, light_zero, n_taps;
+  const float* taps;                       // temporal filter (device), n_taps entries
+  float* out_rgb; float* out_direct; float* out_indirect;               // [n_rays][700][3]
+  float* out_ti_diffuse; float* out_ti_specular;                         // unshifted composites [n_rays][700][3]
+  float* out_direct_rgb; float* out_indirect_rgb; float* out_integrated_rgb;
+  float* out_diffuse_rgb; float* out_specular_rgb; float* out_albedo_rgb; float* out_occ; float* out_indirect_occ;
+  float* out_irradiance_rgb; float* out_light_radiance_rgb; float* out_n_dot_l_rgb; float* out_direct_diffuse_rgb;
+  float* out_direct_specular_rgb; float* out_indirect_diffuse_rgb; float* out_indirect_specular_rgb; float* out_direct_rgb_viz;
+};
+int rc_transient_shader_frags();
+int rc_transient_bins_frags();
+void rc_launch_transient_shader(const RcTransShaderArgs& a, hipStream_t stream);
+void rc_launch_transient_bins(const RcTransBinsArgs& a, hipStream_t stream);

@@ -1,0 +1,623 @@
+// Time-resolved radiance cache (cornell configuration): the TransientNeRFMLP shader and the per-bin
+// compositing of the TransientVolumeIntegrator, fp32 MFMA, gfx950.
+//
+//   k_transient_shader   internal/nerf.py:561-689 (predict_appearance), :691-938 (_predict_appearance_active),
+//                        :1097-1191 (_compute_light_radiance), :1422-1497 (_compute_direct_lighting),
+//                        :484-538 (get_brdf_light), :461-482 (get_integrated_brdf), :1775-1797 (get_indirect trunk),
+//                        internal/surface_light_field.py:480-499, 845-1035 (TransientSurfaceLightFieldMLP trunk)
+//   k_transient_bins     the two 2100-wide heads (nerf.py:1795, surface_light_field.py:1036-1058),
+//                        nerf.py:1692-1771 (_compute_indirect_lighting), render_utils.py:1699-1767 (zero_invalid_bins),
+//                        internal/render.py:250-507 (volumetric_transient_rendering, shift_direct,
+//                        shift_map_coordinates), internal/integration.py:343-551
+//
+// The [rays, samples, 700, 3] per-sample histograms (8.4 KB per sample and key) are never written: the
+// second kernel gives one wavefront to each ray, evaluates the wide heads tile by tile as X W (samples in
+// the MFMA rows, 32 histogram entries in the columns, so a lane owns ONE entry and 16 of the 32 samples),
+// applies activation / travel-time masks / clip, and folds the tile straight into the ray's time-shifted
+// histogram in LDS and into the unshifted per-bin composites.
+#include "rc_dev_mlp.h"
+#include "rc_dev_sample.h"
+
+using namespace rcdev;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// shader: activation steps of a wave (32 samples)
+// ---------------------------------------------------------------------------------------------
+constexpr int kTAct = 117;
+constexpr int T_BIAS0 = 48;    // heads / irradiance-net bias step (1 | 0)
+constexpr int T_LENC = 49;     // [49, 57)  pos_enc(lights): 15 values + an unused slot
+constexpr int T_IRR = 57;      // [57, 90)  irradiance-net hidden layer (32 steps + bias)
+constexpr int T_IDE = 64;      // [64, 100) IDE of the reflection direction
+constexpr int T_WENC = 100;    // [100, 108) pos_enc(contract(lights)): 15 values + bias slot (= 1)
+constexpr int T_DOT = 108;     // (n.(-v) | 1)
+constexpr int T_BENC = 109;    // [109, 117) BRDF encoding: 15 values + bias slot (= 1)
+
+struct TFrags {
+  static constexpr int F_H = 0, F_IR0 = F_H + 49 * 5, F_IR1 = F_IR0 + 57 * 2, F_S0 = F_IR1 + 33 * 2, F_I0 = F_S0 + 108 * 8,
+                       F_I1 = F_I0 + 65 * 2, F_IO = F_I1 + 33 * 2, F_B0 = F_IO + 33, F_B1 = F_B0 + 72 * 2, F_BO = F_B1 + 33 * 2,
+                       F_S1 = F_BO + 33, F_S2 = F_S1 + 65 * 4, F_SB = F_S2 + 65 * 4, COUNT = F_SB + 64 * 4;
+};
+
+// coord.pos_enc(x, 0, 2, append_identity=True) of a 3-vector: [x | sin(x) | sin(2x) | sin(x + pi/2) | sin(2x + pi/2)]
+__device__ __forceinline__ void pos_enc2(const float (&x)[3], float (&e)[16], float slot15) {
+  const float hp = 1.5707963267948966f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float s1 = x[c] * 1.0f, s2 = x[c] * 2.0f;
+    e[c] = x[c];
+    e[3 + c] = sinf(s1);
+    e[6 + c] = sinf(s2);
+    e[9 + c] = sinf(s1 + hp);
+    e[12 + c] = sinf(s2 + hp);
+  }
+  e[15] = slot15;
+}
+// 16 slots as 8 natural activation steps: slot q at step base + q / 2, half-wave q & 1
+__device__ __forceinline__ void stage16(float* act, int base, int h, const float (&e)[16]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) act[(base + i) * 64] = h == 0 ? e[2 * i] : e[2 * i + 1];
+}
+
+__global__ __launch_bounds__(kWaves * 64) void k_transient_shader(RcTransShaderArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t ntiles = (a.n + 31) / 32;
+  int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
+  const bool tile_ok = tile < ntiles;
+  if (!tile_ok) tile = ntiles - 1;
+  float* ring = lds_dyn;
+  float* act = lds_dyn + kRingFloats + wave * (kTAct * 64) + lane;
+  constexpr int NF = TFrags::COUNT;
+  WStream ws{a.wstream, ring, lane, wave};
+  ws_begin<NF>(ws);
+
+  const int64_t p = tile * 32 + j;
+  const bool valid = p < a.n;
+  const int64_t pc = valid ? p : a.n - 1;
+  const int64_t ray = pc / a.samples_per_ray;
+  // ---- inputs: [hidden density feature (accumulator order) | appearance features | bias | pos_enc(lights)]
+  {
+    const float* hb = a.hbuf + (pc >> 5) * (32 * 64) + (pc & 31) + 32 * h;     // [tile][32 steps][64 lanes] (k_density_mlp)
+#pragma unroll
+    for (int s = 0; s < 32; ++s) act[s * 64] = hb[s * 64];
+  }
+#pragma unroll
+  for (int s = 0; s < 16; ++s) act[(32 + s) * 64] = a.app[(int64_t)(2 * s + h) * a.n + pc];
+  act[T_BIAS0 * 64] = h == 0 ? 1.0f : 0.0f;
+  const float lx = a.lights[3 * ray], ly = a.lights[3 * ray + 1], lz = a.lights[3 * ray + 2];
+  {
+    const float l3[3] = {lx, ly, lz};
+    float e[16];
+    pos_enc2(l3, e, 0.0f);
+    stage16(act, T_LENC, h, e);
+  }
+  // ---- heads: bottleneck (4 tiles, linear) + heads tile (0 roughness, 1-3 tint, 4-6 direct tint, 7-9 albedo)
+  f32x16 hd[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) hd[t] = zero16();
+  mlp_layer<5, 49, TFrags::F_H, NF>(ws, act, hd);
+  // ---- irradiance trunk on [feature | pos_enc(lights)] (nerf.py:1781-1791): the inputs are still in place
+  {
+    f32x16 ir[2];
+    ir[0] = zero16(); ir[1] = zero16();
+    mlp_layer<2, 57, TFrags::F_IR0, NF>(ws, act, ir);
+    park<2, true>(ir, act, T_IRR);
+    act[(T_IRR + 32) * 64] = h == 0 ? 1.0f : 0.0f;
+    ir[0] = zero16(); ir[1] = zero16();
+    mlp_layer<2, 33, TFrags::F_IR1, NF>(ws, act + T_IRR * 64, ir);
+    if (tile_ok) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.irr_feat[(tile * 32 + t * 16 + r) * 64 + lane] = fmaxf(ir[t][r], 0.0f);
+    }
+  }
+  const float rough = softplus(hd[4][0] + a.roughness_bias);                   // nerf.py:633-634
+  const float tint[3] = {sigmoidf(hd[4][1]), sigmoidf(hd[4][2]), sigmoidf(hd[4][3])};          // nerf.py:1697
+  const float dtint[3] = {sigmoidf(hd[4][4]), sigmoidf(hd[4][5]), sigmoidf(hd[4][6])};         // nerf.py:1469
+  const float albedo[3] = {softplus(hd[4][7] + a.albedo_bias), softplus(hd[4][8] + a.albedo_bias),
+                           softplus(hd[4][9] + a.albedo_bias)};                                // nerf.py:1466-1468
+  {
+    f32x16 bt[4] = {hd[0], hd[1], hd[2], hd[3]};
+    park<4, false>(bt, act, 0);
+  }
+  // ---- geometry of this lane's sample
+  const float mx = a.means[pc], my = a.means[a.n + pc], mz = a.means[2 * a.n + pc];
+  const float nx = a.normals[pc], ny = a.normals[a.n + pc], nz = a.normals[2 * a.n + pc];
+  const float vx = a.viewdirs[3 * ray], vy = a.viewdirs[3 * ray + 1], vz = a.viewdirs[3 * ray + 2];
+  const float ox = a.origins[3 * ray], oy = a.origins[3 * ray + 1], oz = a.origins[3 * ray + 2];
+  const float lox = lx - mx, loy = ly - my, loz = lz - mz;                    // nerf.py:717-722
+  const float ldist = sqrtf(lox * lox + loy * loy + loz * loz);
+  const float ldn = fmaxf(ldist, 1e-5f);
+  const float ldx = lox / ldn, ldy = loy / ldn, ldz = loz / ldn;
+  const float rdist = sqrtf((ox - mx) * (ox - mx) + (oy - my) * (oy - my) + (oz - mz) * (oz - mz));
+  const float cox = ox - a.cam_origins[3 * ray], coy = oy - a.cam_origins[3 * ray + 1], coz = oz - a.cam_origins[3 * ray + 2];
+  const float camdist = rdist + sqrtf(cox * cox + coy * coy + coz * coz);     // render_utils.py:1731-1740
+  // light radiance (nerf.py:1142-1171): power = safe_exp(light_power), 1/d^2, light_zero
+  float radiance = 1.0f * expf(fminf(a.light_power, 70.0f));
+  if (a.use_falloff) radiance = radiance * (1.0f / fmaxf(ldist * ldist, 1e-5f));
+  if (a.light_zero && ldist < a.light_near) radiance = 0.0f;
+  const float radiance_before_occ = radiance;
+  const float n_dot_l = fmaxf(0.0f, nx * ldx + ny * ldy + nz * ldz);          // nerf.py:744
+  float occ = a.occ ? a.occ[pc] : 0.0f;
+  if (n_dot_l <= 0.0f) occ = 1.0f;                                            // nerf.py:764
+  radiance = radiance * (1.0f - occ);
+  const float dotp = nx * (-vx) + ny * (-vy) + nz * (-vz);
+  {
+    // BRDF-light input (nerf.py:495-523): sort(n.v, n.l), n.h with h = normalize(-v + l)
+    const float hx = -vx + ldx, hy = -vy + ldy, hz = -vz + ldz;
+    const float hn = sqrtf(hx * hx + hy * hy + hz * hz);
+    const float ndl = nx * ldx + ny * ldy + nz * ldz;
+    const float ndh = nx * (hx / hn) + ny * (hy / hn) + nz * (hz / hn);
+    const float b3[3] = {fminf(dotp, ndl), fmaxf(dotp, ndl), ndh};
+    float e[16];
+    pos_enc2(b3, e, 1.0f);
+    stage16(act, T_BENC, h, e);
+    // lights for the surface light field: warp_fn = contract (surface_light_field.py:1022-1024)
+    float w3[3] = {lx, ly, lz};
+    contract3(w3[0], w3[1], w3[2], a.contract_radius);
+    pos_enc2(w3, e, 1.0f);
+    stage16(act, T_WENC, h, e);
+    act[T_DOT * 64] = h == 0 ? dotp : 1.0f;
+  }
+  {
+    // IDE of reflect(-v, n) (ref_utils.py:25-42, 155-190), as in shader_tile
+    const float rx = 2.0f * dotp * nx - (-vx), ry = 2.0f * dotp * ny - (-vy), rz = 2.0f * dotp * nz - (-vz);
+    const RcIdeTable* tb = reinterpret_cast<const RcIdeTable*>(a.ide_coef);
+    float zp[RC_IDE_ZPOW];
+    zp[0] = 1.0f;
+#pragma unroll
+    for (int k = 1; k < RC_IDE_ZPOW; ++k) zp[k] = zp[k - 1] * rz;
+    float cpw[RC_IDE_ZPOW];
+    {
+      float cre = 1.0f, cim = 0.0f;
+      cpw[0] = h == 0 ? cre : cim;
+#pragma unroll
+      for (int m = 1; m < RC_IDE_ZPOW; ++m) {
+        const float nre = cre * rx - cim * ry;
+        const float nim = cre * ry + cim * rx;
+        cre = nre; cim = nim;
+        cpw[m] = h == 0 ? cre : cim;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RC_IDE_TERMS; ++i) {
+      const int l = ide_l(i), m = ide_m(i);
+      float poly = 0.0f;
+#pragma unroll
+      for (int k = 0; k < RC_IDE_ZPOW; ++k)
+        if (k <= l - m && ((l - m - k) & 1) == 0) poly = poly + zp[k] * tb->coef[i][k];
+      const float att = expf(-(0.5f * (float)(l * (l + 1))) * rough);
+      act[(T_IDE + i) * 64] = (cpw[m] * poly) * att;
+    }
+  }
+  // ---- SLF layer_0 (tiles 0-3) + input part of layer_bottleneck (tiles 4-7) over [bottleneck | IDE | lights]
+  f32x16 s0[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) s0[t] = zero16();
+  mlp_layer<8, 108, TFrags::F_S0, NF>(ws, act, s0);
+  // ---- integrated BRDF (nerf.py:461-482); scratch [64, 97)
+  float ibrdf;
+  {
+    f32x16 ib[2];
+    ib[0] = zero16(); ib[1] = zero16();
+    mlp_layer<2, 64, TFrags::F_I0, NF>(ws, act, ib);
+    mlp_layer<2, 1, TFrags::F_I0 + 128, NF>(ws, act + T_DOT * 64, ib);
+    park<2, true>(ib, act, 64);
+    act[(64 + 32) * 64] = h == 0 ? 1.0f : 0.0f;
+    ib[0] = zero16(); ib[1] = zero16();
+    mlp_layer<2, 33, TFrags::F_I1, NF>(ws, act + 64 * 64, ib);
+    park<2, true>(ib, act, 64);
+    f32x16 o[1];
+    o[0] = zero16();
+    mlp_layer<1, 33, TFrags::F_IO, NF>(ws, act + 64 * 64, o);
+    ibrdf = sigmoidf(o[0][0] + 1.0986123f);
+  }
+  // ---- BRDF towards the light (nerf.py:484-538): [bottleneck | enc(sorted dots, n.h)] -> 64 -> 64 -> 1
+  float lbrdf;
+  {
+    f32x16 b[2];
+    b[0] = zero16(); b[1] = zero16();
+    mlp_layer<2, 64, TFrags::F_B0, NF>(ws, act, b);
+    mlp_layer<2, 8, TFrags::F_B0 + 128, NF>(ws, act + T_BENC * 64, b);
+    park<2, true>(b, act, 64);
+    act[(64 + 32) * 64] = h == 0 ? 1.0f : 0.0f;
+    b[0] = zero16(); b[1] = zero16();
+    mlp_layer<2, 33, TFrags::F_B1, NF>(ws, act + 64 * 64, b);
+    park<2, true>(b, act, 64);
+    f32x16 o[1];
+    o[0] = zero16();
+    mlp_layer<1, 33, TFrags::F_BO, NF>(ws, act + 64 * 64, o);
+    lbrdf = softplus(o[0][0] + a.brdf_bias);
+    if (n_dot_l == 0.0f) lbrdf = 0.0f;                                        // nerf.py:1478-1481
+  }
+  // ---- SLF trunk: layer_1, layer_2, layer_bottleneck -> the 128-wide feature of the wide output layer
+  {
+    f32x16 acc[4] = {s0[0], s0[1], s0[2], s0[3]};
+    f32x16 skip[4] = {s0[4], s0[5], s0[6], s0[7]};
+    park<4, true>(acc, act, 0);
+    act[64 * 64] = h == 0 ? 1.0f : 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = zero16();
+    mlp_layer<4, 65, TFrags::F_S1, NF>(ws, act, acc);
+    park<4, true>(acc, act, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = zero16();
+    mlp_layer<4, 65, TFrags::F_S2, NF>(ws, act, acc);
+    park<4, true>(acc, act, 0);
+    mlp_layer<4, 64, TFrags::F_SB, NF>(ws, act, skip);
+    if (tile_ok) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.slf_feat[(tile * 64 + t * 16 + r) * 64 + lane] = fmaxf(skip[t][r], 0.0f);
+    }
+  }
+  if (valid && tile_ok && h == 0) {
+    float* o = a.tshade + p;
+    const int64_t n = a.n;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      // nerf.py:1483-1488 (direct_diffuse, direct_specular clipped to [0, rgb_max])
+      o[(RC_TS_DD + c) * n] = fminf(fmaxf(((albedo[c] * n_dot_l) * radiance) / 3.14159265358979323846f, 0.0f), a.rgb_max);
+      o[(RC_TS_DS + c) * n] = fminf(fmaxf((dtint[c] * lbrdf) * radiance, 0.0f), a.rgb_max);
+      o[(RC_TS_ALBEDO + c) * n] = albedo[c];
+      o[(RC_TS_TIB + c) * n] = tint[c] * ibrdf;
+    }
+    o[RC_TS_ROUGH * n] = rough;
+    o[RC_TS_NDOTL * n] = n_dot_l;
+    o[RC_TS_IRRAD * n] = (n_dot_l * radiance_before_occ) / 3.14159265358979323846f;      // nerf.py:921-925
+    o[RC_TS_OCC * n] = occ;
+    o[RC_TS_LDIST * n] = ldist;
+    o[RC_TS_RDIST * n] = rdist;
+    o[RC_TS_CAMDIST * n] = camdist;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-bin heads + compositing: one wavefront per ray
+// ---------------------------------------------------------------------------------------------
+constexpr int kBins = 700;
+constexpr int kHist = kBins * 3;                 // 2100 histogram entries per ray, entry = bin * 3 + channel
+constexpr int kTilesB = (kHist + 31) / 32;       // 66 column tiles
+constexpr int kFragsPerTile = 65 + 33;           // SLF output layer (128 + bias) | transient_indirect_layer (64 + bias)
+constexpr int kBinFrags = kTilesB * kFragsPerTile;
+constexpr int kSP = 8;                           // per-sample parameters kept in LDS
+constexpr int kWaveLds = 2 * kHist + kSP * 32 + 6 * 32;   // floats: indirect hist, direct hist, params, bin sums
+
+__device__ __forceinline__ void ws_issue_rt(const WStream& w, int c, int nf) {
+#pragma unroll
+  for (int k = 0; k < kChunk / 4 / kWaves; ++k) {
+    const int i = w.wave + kWaves * k;
+    const int frag0 = c * kChunk + 4 * i;
+    if (frag0 < nf) {
+      const float* src = w.g + (size_t)frag0 * 64 + w.lane * 4;
+      float* dst = w.ring + ((c & 1) * kChunk + 4 * i) * 64;
+      __builtin_amdgcn_global_load_lds((const void*)src, (lds_void_ptr)dst, 16, 0, 0);
+    }
+  }
+}
+// fragment f of the stream (f advances by one per call, uniformly over the workgroup)
+__device__ __forceinline__ float ws_next(const WStream& w, int f, int nf) {
+  if (f > 0 && (f & (kChunk - 1)) == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int c = f / kChunk;
+    if ((c + 1) * kChunk < nf) ws_issue_rt(w, c + 1, nf);
+  }
+  return w.ring[(f & (2 * kChunk - 1)) * 64 + w.lane];
+}
+
+// X W for one column tile: KS k-steps with the activations in registers, fragments [f0, f0 + KS)
+template <int KS>
+__device__ __forceinline__ void tile_xw(const WStream& w, int f0, int nf, const float (&x)[KS], f32x16& acc) {
+  constexpr int SG = 4, NG = (KS + SG - 1) / SG;
+  float b[2][SG];
+  auto load = [&](int g, int buf) {
+#pragma unroll
+    for (int d = 0; d < SG; ++d)
+      if (g * SG + d < KS) b[buf][d] = ws_next(w, f0 + g * SG + d, nf);
+  };
+  load(0, 0);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) load(g + 1, (g + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < SG; ++d)
+      if (g * SG + d < KS) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[g * SG + d], b[g & 1][d], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int fl = lane & 31, h = lane >> 5;
+  int64_t ray = (int64_t)blockIdx.x * kWaves + wave;
+  const bool ray_ok = ray < a.n_rays;
+  if (!ray_ok) ray = a.n_rays - 1;
+  const int64_t n = a.n_rays * 32;                 // samples
+  float* ring = lds_dyn;
+  float* wl = lds_dyn + kRingFloats + wave * kWaveLds;
+  float* hist_i = wl;                              // time-shifted indirect histogram
+  float* hist_d = wl + kHist;                      // direct histogram (before the temporal filter)
+  float* sp = wl + 2 * kHist;                      // [kSP][32] per-sample parameters
+  float* bsum = sp + kSP * 32;                     // [6][32] per-sample sums over bins (diffuse rgb, specular rgb)
+  enum { P_W = 0, P_LDIST, P_CAMDIST, P_TIB0, P_TIB1, P_TIB2, P_DIND, P_KILL };
+  WStream ws{a.wstream, ring, lane, wave};
+  ws_issue_rt(ws, 0, kBinFrags);
+  for (int e = lane; e < 2 * kHist; e += 64) wl[e] = 0.0f;
+  if (lane < 32) {
+    const int64_t p = ray * 32 + lane;
+    const float ld = a.tshade[RC_TS_LDIST * n + p];
+    sp[P_W * 32 + lane] = a.weights[p];
+    sp[P_LDIST * 32 + lane] = ld;
+    sp[P_CAMDIST * 32 + lane] = a.tshade[RC_TS_CAMDIST * n + p];
+    sp[P_TIB0 * 32 + lane] = a.tshade[(RC_TS_TIB + 0) * n + p];
+    sp[P_TIB1 * 32 + lane] = a.tshade[(RC_TS_TIB + 1) * n + p];
+    sp[P_TIB2 * 32 + lane] = a.tshade[(RC_TS_TIB + 2) * n + p];
+    // bins_move / exposure_time (render.py:483): ray_dist + shift, divided by the exposure
+    sp[P_DIND * 32 + lane] = (a.tshade[RC_TS_RDIST * n + p] + a.shift) / a.exposure;
+    sp[P_KILL * 32 + lane] = (a.light_zero && ld < a.light_near) ? 1.0f : 0.0f;      // render_utils.py:1750-1760
+  }
+  // activations of the two output layers (this ray's 32 samples), with the bias step
+  float xs[65], xi[33];
+#pragma unroll
+  for (int s = 0; s < 64; ++s) xs[s] = a.slf_feat[(ray * 64 + s) * 64 + lane];
+  xs[64] = h == 0 ? 1.0f : 0.0f;
+#pragma unroll
+  for (int s = 0; s < 32; ++s) xi[s] = a.irr_feat[(ray * 32 + s) * 64 + lane];
+  xi[32] = h == 0 ? 1.0f : 0.0f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (kChunk < kBinFrags) ws_issue_rt(ws, 1, kBinFrags);
+
+  const float max_dists = a.max_dists;
+  // per-sample sums over the bins: by tile phase u = T % 3 (the channel of a lane's entry is (2 u + fl) % 3)
+  float sd[3][16], ss[3][16];
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sd[u][r] = 0.0f; ss[u][r] = 0.0f; }
+
+  auto tile_body = [&](const int T, float (&sdu)[16], float (&ssu)[16]) __attribute__((always_inline)) {
+    {
+      f32x16 as = zero16(), ai = zero16();
+      tile_xw<65>(ws, T * kFragsPerTile, kBinFrags, xs, as);
+      tile_xw<33>(ws, T * kFragsPerTile + 65, kBinFrags, xi, ai);
+      const int f = T * 32 + fl;                   // histogram entry of this lane
+      const bool fok = f < kHist;
+      const int b = f / 3, c = f - 3 * b;
+      const float hist_light = (float)(b + a.bin_zero_threshold_light) * a.exposure;   // render_utils.py:1713
+      const float hist_cam = (float)b * a.exposure;                                    // :1729
+      float cd = 0.0f, cs = 0.0f;                  // unshifted composites over this half-wave's 16 samples
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float w = sp[P_W * 32 + i];
+        // nerf.py:1795-1797 and :1712-1719: softplus(. + irradiance_bias) * indirect_scale;
+        // surface_light_field.py:1037-1058 and nerf.py:1721-1723: tint * ibrdf * clip(softplus(. + rgb_bias), 0) * scale
+        float diff = softplus(ai[r] + a.irradiance_bias) * a.indirect_scale;
+        const float ref = fmaxf(softplus(1.0f * as[r] + a.slf_rgb_bias), 0.0f);
+        const float tib = c == 0 ? sp[P_TIB0 * 32 + i] : (c == 1 ? sp[P_TIB1 * 32 + i] : sp[P_TIB2 * 32 + i]);
+        float spec = (tib * ref) * a.indirect_scale;
+        // zero_invalid_bins (render_utils.py:1699-1767)
+        const bool kill = (hist_light < sp[P_LDIST * 32 + i]) | ((hist_cam + sp[P_CAMDIST * 32 + i]) > max_dists) |
+                          (sp[P_KILL * 32 + i] != 0.0f) | !fok;
+        diff = kill ? 0.0f : fminf(fmaxf(diff, 0.0f), a.rgb_max);             // nerf.py:1757-1758
+        spec = kill ? 0.0f : fminf(fmaxf(spec, 0.0f), a.rgb_max);
+        sdu[r] += diff; ssu[r] += spec;
+        cd += w * diff; cs += w * spec;
+        // shift_map_coordinates (render.py:480-496): out[y] = in(y - d), linear, zero outside.  Entry b of this
+        // sample reaches y = b + floor(d) and y + 1; the weights are those the target bin computes.
+        const float dmove = sp[P_DIND * 32 + i];
+        const int y0 = b + (int)floorf(dmove);
+        const float val = w * (diff + spec);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int y = y0 + k;
+          const float t = (float)y - dmove;
+          const float i0 = floorf(t);
+          const float fw = t - i0;
+          const float wt = ((int)i0 == b ? 1.0f - fw : 0.0f) + ((int)i0 + 1 == b ? fw : 0.0f);
+          const bool ok = fok && y >= 0 && y < kBins;
+          // the two half-waves work on different samples and may meet in one entry: one after the other
+          // (within a half-wave the 32 lanes hold 32 different entries of ONE sample: plain read-add-write)
+          if (ok && h == 0) hist_i[y * 3 + c] = hist_i[y * 3 + c] + val * wt;
+          if (ok && h == 1) hist_i[y * 3 + c] = hist_i[y * 3 + c] + val * wt;
+        }
+      }
+      cd += __shfl_xor(cd, 32, 64);
+      cs += __shfl_xor(cs, 32, 64);
+      if (h == 0 && fok && ray_ok) {
+        if (a.out_ti_diffuse) a.out_ti_diffuse[ray * kHist + f] = cd;
+        if (a.out_ti_specular) a.out_ti_specular[ray * kHist + f] = cs;
+      }
+    }
+  };
+  for (int T3 = 0; T3 < kTilesB / 3; ++T3) {
+    tile_body(T3 * 3 + 0, sd[0], ss[0]);
+    tile_body(T3 * 3 + 1, sd[1], ss[1]);
+    tile_body(T3 * 3 + 2, sd[2], ss[2]);
+  }
+  // ---- per-sample sums over the bins: pick the channel of each tile phase, add up the 32 entry lanes
+  {
+    float v[6][16];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float d = 0.0f, s = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const bool mine = (2 * u + fl) % 3 == c;
+          d += mine ? sd[u][r] : 0.0f;
+          s += mine ? ss[u][r] : 0.0f;
+        }
+        v[c][r] = d; v[3 + c][r] = s;
+      }
+#pragma unroll
+    for (int dl = 16; dl >= 1; dl >>= 1)
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[q][r] += __shfl_xor(v[q][r], dl, 64);
+    if (fl == 0) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bsum[q * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = v[q][r];
+    }
+  }
+  lds_sync<false>();
+  // ---- direct light: scatter at (ray_dist + light_dist) / exposure with floor / ceil weights (render.py:436-477).
+  //      The reference indexes the flattened [rays * bins] array: bins >= 700 of the previous ray of the batch
+  //      land at the start of this ray's histogram.
+  {
+    // lanes 0-31 prepare the samples of the previous ray, lanes 32-63 those of this ray; lanes 0-2 (one per
+    // channel) then add the 64 contributions in that order
+    const int64_t sr = ray - 1 + h;
+    int il = -1, ih = -1;
+    float vl[3] = {0.0f, 0.0f, 0.0f}, vh[3] = {0.0f, 0.0f, 0.0f};
+    if (sr >= 0) {
+      const int64_t p = sr * 32 + fl;
+      const float d = (a.tshade[RC_TS_LDIST * n + p] + a.tshade[RC_TS_RDIST * n + p]) / a.exposure + a.shift / a.exposure;
+      const float low = fmaxf(floorf(d), 0.0f), high = ceilf(d);
+      const float w_high = d - low, w_low = 1.0f - w_high;
+      const int off = h == 0 ? kBins : 0;
+      il = (int)low - off; ih = (int)high - off;
+      if (il < 0 || il >= kBins) il = -1;
+      if (ih < 0 || ih >= kBins) ih = -1;
+      const float w = a.weights[p];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float val = w * (a.tshade[(RC_TS_DD + c) * n + p] + a.tshade[(RC_TS_DS + c) * n + p]);
+        vl[c] = val * w_low; vh[c] = val * w_high;
+      }
+    }
+    auto bc_i = [](int v, int l) { return __builtin_amdgcn_readlane(v, l); };
+    auto bc_f = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+#pragma unroll
+    for (int sidx = 0; sidx < 64; ++sidx) {
+      const int bl = bc_i(il, sidx), bh = bc_i(ih, sidx);
+      const float l0 = bc_f(vl[0], sidx), l1 = bc_f(vl[1], sidx), l2 = bc_f(vl[2], sidx);
+      const float h0 = bc_f(vh[0], sidx), h1 = bc_f(vh[1], sidx), h2 = bc_f(vh[2], sidx);
+      if (lane < 3) {
+        const float lo = lane == 0 ? l0 : (lane == 1 ? l1 : l2);
+        const float hi = lane == 0 ? h0 : (lane == 1 ? h1 : h2);
+        if (bl >= 0) hist_d[bl * 3 + lane] = hist_d[bl * 3 + lane] + lo;
+        if (bh >= 0) hist_d[bh * 3 + lane] = hist_d[bh * 3 + lane] + hi;
+      }
+    }
+  }
+  lds_sync<false>();
+  // ---- temporal filter on the direct part (render.py:406-417), outputs, sums over bins
+  float sum_d[3] = {0.0f, 0.0f, 0.0f}, sum_i[3] = {0.0f, 0.0f, 0.0f};
+  for (int e = lane; e < kHist; e += 64) {
+    const int b = e / 3, c = e - 3 * b;
+    float dv;
+    if (a.n_taps > 0) {
+      dv = 0.0f;
+      const int half = (a.n_taps - 1) / 2;
+      for (int k = 0; k < a.n_taps; ++k) {
+        const int yb = b - (k - half);
+        if (yb >= 0 && yb < kBins) dv += a.taps[k] * hist_d[yb * 3 + c];
+      }
+    } else {
+      dv = hist_d[e];
+    }
+    const float iv = hist_i[e];
+    if (ray_ok) {
+      if (a.out_rgb) a.out_rgb[ray * kHist + e] = dv + iv;
+      if (a.out_direct) a.out_direct[ray * kHist + e] = dv;
+      if (a.out_indirect) a.out_indirect[ray * kHist + e] = iv;
+    }
+    sum_d[c] += dv; sum_i[c] += iv;
+  }
+  {
+    float v[6] = {sum_d[0], sum_d[1], sum_d[2], sum_i[0], sum_i[1], sum_i[2]};
+    wave_sum_n<6>(v);
+    if (lane == 0 && ray_ok) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (a.out_direct_rgb) a.out_direct_rgb[3 * ray + c] = v[c];
+        if (a.out_indirect_rgb) a.out_indirect_rgb[3 * ray + c] = v[3 + c];
+        if (a.out_integrated_rgb) a.out_integrated_rgb[3 * ray + c] = v[c] + v[3 + c];
+      }
+    }
+  }
+  // ---- per-sample extras composited with the sample weights (integration.py:420-470, render.py:283-299)
+  {
+    const bool act_s = lane < 32;
+    const int64_t p = ray * 32 + (act_s ? lane : 0);
+    const float w = act_s ? a.weights[p] : 0.0f;
+    auto ts = [&](int ch) { return a.tshade[(int64_t)ch * n + p]; };
+    enum { E_DIFF = 0, E_SPEC = 3, E_ALB = 6, E_OCC = 9, E_IRR = 10, E_NDL = 11, E_DD = 12, E_DS = 15, E_ID = 18, E_IS = 21,
+           E_DVIZ = 24, E_W = 27, E_COUNT = 28 };
+    float v[E_COUNT];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float dd = ts(RC_TS_DD + c), ds = ts(RC_TS_DS + c);
+      const float idf = bsum[c * 32 + (lane & 31)], isp = bsum[(3 + c) * 32 + (lane & 31)];
+      v[E_DIFF + c] = w * (dd + idf + 0.0f);                                   // nerf.py:875
+      v[E_SPEC + c] = w * (ds + isp + 0.0f);
+      v[E_ALB + c] = w * ts(RC_TS_ALBEDO + c);
+      v[E_DD + c] = w * dd; v[E_DS + c] = w * ds;
+      v[E_ID + c] = w * (idf + 0.0f); v[E_IS + c] = w * (isp + 0.0f);
+      v[E_DVIZ + c] = act_s ? dd + ds : 0.0f;                                  // direct_rgb_viz: plain sum over samples
+    }
+    v[E_OCC] = w * ts(RC_TS_OCC);
+    v[E_IRR] = w * ts(RC_TS_IRRAD);
+    v[E_NDL] = w * ts(RC_TS_NDOTL);
+    v[E_W] = w;
+    wave_sum_n<E_COUNT>(v);
+    if (lane == 0 && ray_ok) {
+      auto st3 = [&](float* o, float x, float y, float z) { if (o) { o[3 * ray] = x; o[3 * ray + 1] = y; o[3 * ray + 2] = z; } };
+      st3(a.out_diffuse_rgb, v[E_DIFF], v[E_DIFF + 1], v[E_DIFF + 2]);
+      st3(a.out_specular_rgb, v[E_SPEC], v[E_SPEC + 1], v[E_SPEC + 2]);
+      st3(a.out_albedo_rgb, v[E_ALB], v[E_ALB + 1], v[E_ALB + 2]);
+      st3(a.out_occ, v[E_OCC], v[E_OCC], v[E_OCC]);
+      st3(a.out_irradiance_rgb, v[E_IRR], v[E_IRR], v[E_IRR]);
+      st3(a.out_n_dot_l_rgb, v[E_NDL], v[E_NDL], v[E_NDL]);
+      st3(a.out_direct_diffuse_rgb, v[E_DD], v[E_DD + 1], v[E_DD + 2]);
+      st3(a.out_direct_specular_rgb, v[E_DS], v[E_DS + 1], v[E_DS + 2]);
+      st3(a.out_indirect_diffuse_rgb, v[E_ID], v[E_ID + 1], v[E_ID + 2]);
+      st3(a.out_indirect_specular_rgb, v[E_IS], v[E_IS + 1], v[E_IS + 2]);
+      st3(a.out_direct_rgb_viz, v[E_DVIZ], v[E_DVIZ + 1], v[E_DVIZ + 2]);
+      st3(a.out_indirect_occ, v[E_W], v[E_W], v[E_W]);          // incoming_acc == 1 (surface_light_field.py:887,1067)
+      st3(a.out_light_radiance_rgb, v[E_W], v[E_W], v[E_W]);    // light_radiance_mult == 1 (nerf.py:1118)
+    }
+  }
+}
+
+}  // namespace
+
+int rc_transient_shader_frags() { return TFrags::COUNT; }
+int rc_transient_bins_frags() { return kBinFrags; }
+
+void rc_launch_transient_shader(const RcTransShaderArgs& a, hipStream_t stream) {
+  if (a.n <= 0) return;
+  static bool prepared = false;
+  const int lds = (kRingFloats + kWaves * kTAct * 64) * (int)sizeof(float);
+  if (!prepared) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_transient_shader), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    prepared = true;
+  }
+  const int64_t ntiles = (a.n + 31) / 32;
+  hipLaunchKernelGGL(k_transient_shader, dim3((unsigned)((ntiles + kWaves - 1) / kWaves)), dim3(kWaves * 64), lds, stream, a);
+}
+
+void rc_launch_transient_bins(const RcTransBinsArgs& a, hipStream_t stream) {
+  if (a.n_rays <= 0) return;
+  static bool prepared = false;
+  const int lds = (kRingFloats + kWaves * kWaveLds) * (int)sizeof(float);
+  if (!prepared) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_transient_bins), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    prepared = true;
+  }
+  hipLaunchKernelGGL(k_transient_bins, dim3((unsigned)((a.n_rays + kWaves - 1) / kWaves)), dim3(kWaves * 64), lds, stream, a);
+}

@@ -99,6 +99,8 @@ class Model:
             raise NotImplementedError("sampling_strategy is fixed when the handle is created")
         if "material" in passes:
             return self._apply_material(variables, rng, rays)
+        if self.config.transient is not None:
+            return self._apply_transient(variables, rng, rays, is_secondary or "is_secondary" in passes, resample)
         if variables is not None and id(variables) != self._variables_id:
             self.load_variables(variables)
         fields = rays.hot_fields() if isinstance(rays, Rays) else dict(rays)
@@ -125,6 +127,41 @@ class Model:
         return {"render": render, "main": {"integrator": render}, "cache_main": {"integrator": render}}
 
     __call__ = apply
+
+    def _apply_transient(self, variables, rng, rays, is_secondary, resample):
+        """TransientNeRFModel (internal/models.py:912-985) as the cache of TransientMaterialModel with
+        use_material=False: sampler -> TransientNeRFMLP -> TransientVolumeIntegrator on primary rays.
+        `rgb` is the [n, n_bins, 3] transient; models.render_image drops every other `transient*` key except
+        the two `*_viz` ones (internal/models.py:2403, 2459-2472)."""
+        import torch
+
+        if is_secondary or resample:
+            raise NotImplementedError("the time-resolved cache renders primary rays without resampling "
+                                      "(TransientNeRFModel.resample_render = False)")
+        if variables is not None and id(variables) != self._variables_id:
+            self.load_variables(variables)
+        fields = rays.hot_fields() if isinstance(rays, Rays) else dict(rays)
+        if fields.get("lights") is None or fields.get("cam_origins") is None:
+            raise ValueError("transient rays need `lights` and `cam_origins`")
+        n = int(np.prod(np.shape(fields["near"])))
+        randoms, _ = _draw_randoms(rng, n, self.config, False)
+        r = dict(self.rc.render_transient(fields, randoms))
+        zeros3 = torch.zeros_like(r["integrated_rgb"])
+        r["transient_indirect"] = r["transient_indirect_viz"]           # render.py:503 (final value of the key)
+        r["transient_direct"] = r["transient_direct_viz"]               # dark_level = 0
+        for k in ("ambient_rgb", "ambient_diffuse_rgb", "ambient_specular_rgb"):   # use_ambient = False
+            r[k] = zeros3
+        r["normals_to_use"] = r["normals_pred"]
+        r["ray_dists"] = r["ray_dists"][:, None]
+        r["light_dists"] = r["light_dists"][:, None]
+        for k in _FINAL_INTEGRATOR_KEYS:
+            if k in r:
+                r["cache_" + k] = r[k]
+        r["vignette"] = torch.ones_like(r["integrated_rgb"][:, :1])
+        lossmult = fields.get("lossmult")
+        lm = torch.ones_like(r["vignette"]) if lossmult is None else self.rc._dev(lossmult).reshape(-1, 1)
+        r["lossmult"] = lm * torch.ones_like(r["integrated_rgb"])
+        return {"render": r, "main": {"integrator": r}, "cache_main": {"integrator": r}}
 
     def _apply_material(self, variables, rng, rays):
         """passes ("cache", "light", "material") with use_material / use_light_sampler /

@@ -54,6 +54,8 @@ class Rays:
         """The fields the hot path consumes, as a plain dict."""
         d = dict(origins=self.origins, directions=self.directions, viewdirs=self.viewdirs,
                  near=self.near, far=self.far, lights=self.lights, lossmult=self.lossmult)
+        if self.cam_origins is not None:
+            d["cam_origins"] = self.cam_origins      # transient only (render_utils.py:1733-1740)
         if self.normals is not None:
             d["normals"] = self.normals
         return d
@@ -93,6 +95,18 @@ def synthetic_rays(n_rays: int, seed: int = 20200823, near: float = 2.0, far: fl
         radii=f32(ones * 5.2e-4), imageplane=f32(np.zeros((n_rays, 2))), look=f32(look), up=f32(up),
         cam_origins=f32(o), vcam_look=f32(look), vcam_up=f32(up), vcam_origins=f32(o),
         lossmult=f32(ones), near=f32(ones * near), far=f32(ones * far), cam_idx=zi, light_idx=zi.copy())
+
+
+def synthetic_transient_rays(n_rays: int, seed: int = 20200823, near: float = 0.7, far: float = 4.0) -> Rays:
+    """Random primary rays of a simulated transient capture (cornell scale, Config.near/far of
+    transient_simulation_ngp_yobo_cornell.gin:28-32): cameras on a radius-2.5 shell looking at a radius-0.6
+    ball, a point light next to each camera (`lights`), `cam_origins` = the camera centre."""
+    r = synthetic_rays(n_rays, seed, near, far)
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    scale = np.float32(2.5 / 4.03)
+    o = r.origins * scale
+    lights = (o + rng.normal(scale=0.05, size=o.shape)).astype(np.float32)
+    return dataclasses.replace(r, origins=o, cam_origins=o.copy(), vcam_origins=o.copy(), lights=lights)
 
 
 def synthetic_camera_rays(height: int, width: int, focal: float = 1111.0, cam_origin=(0.0, -3.5, 2.0),

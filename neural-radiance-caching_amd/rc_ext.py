@@ -95,10 +95,38 @@ class rc_mat_outputs(C.Structure):
     _fields_ = [("ptr", C.c_void_p * RC_MOUT_COUNT)]
 
 
+class rc_transient_config(C.Structure):
+    _fields_ = [("n_bins", C.c_int32), ("exposure_time", C.c_float), ("tfilter_sigma", C.c_float),
+                ("transient_shift", C.c_float), ("bin_zero_threshold_light", C.c_int32), ("light_near", C.c_float),
+                ("light_zero", C.c_int32), ("use_falloff", C.c_int32), ("indirect_scale", C.c_float),
+                ("rgb_max", C.c_float), ("albedo_bias", C.c_float), ("brdf_bias", C.c_float),
+                ("irradiance_bias", C.c_float), ("slf_rgb_bias", C.c_float), ("use_occlusions", C.c_int32),
+                ("reserved", C.c_int32 * 9)]
+
+
+# rc_transient_output_id -> (name, trailing shape); order must match include/rc_abi.h
+TRANSIENT_OUTPUTS = (
+    ("rgb", "bins"), ("transient_direct_viz", "bins"), ("transient_indirect_viz", "bins"),
+    ("transient_indirect_diffuse", "bins"), ("transient_indirect_specular", "bins"), ("integrated_rgb", 3),
+    ("direct_rgb", 3), ("indirect_rgb", 3), ("diffuse_rgb", 3), ("specular_rgb", 3), ("albedo_rgb", 3), ("occ", 3),
+    ("indirect_occ", 3), ("irradiance_rgb", 3), ("light_radiance_rgb", 3), ("n_dot_l_rgb", 3),
+    ("direct_diffuse_rgb", 3), ("direct_specular_rgb", 3), ("indirect_diffuse_rgb", 3), ("indirect_specular_rgb", 3),
+    ("direct_rgb_viz", 3), ("acc", 1), ("distance_mean", 1), ("distance_median", 1), ("distance_percentile_5", 1),
+    ("distance_percentile_95", 1), ("means", 3), ("normals", 3), ("normals_pred", 3), ("ray_dists", 1),
+    ("light_dists", 1),
+)
+TRANSIENT_OUTPUT_ID = {name: i for i, (name, _) in enumerate(TRANSIENT_OUTPUTS)}
+RC_TOUT_COUNT = len(TRANSIENT_OUTPUTS)
+
+
+class rc_transient_outputs(C.Structure):
+    _fields_ = [("ptr", C.c_void_p * RC_TOUT_COUNT)]
+
+
 EXPORTS = (
     "rc_create", "rc_destroy", "rc_last_error", "rc_abi_version", "rc_load_weights", "rc_render_rays",
     "rc_hashgrid_lookup", "rc_sample_intervals", "rc_workspace_ptr", "rc_set_profiling", "rc_stage_count",
-    "rc_stage_name", "rc_stage_times_ms", "rc_set_graph_mode", "rc_set_fused", "rc_render_material",
+    "rc_stage_name", "rc_stage_times_ms", "rc_set_graph_mode", "rc_set_fused", "rc_render_material", "rc_set_transient", "rc_render_transient",
 )
 
 _LIB = None
@@ -148,6 +176,10 @@ def load_library():
     lib.rc_set_graph_mode.restype = C.c_int
     lib.rc_set_fused.argtypes = [C.c_void_p, C.c_int32]
     lib.rc_set_fused.restype = C.c_int
+    lib.rc_set_transient.argtypes = [C.c_void_p, C.c_void_p]
+    lib.rc_set_transient.restype = C.c_int
+    lib.rc_render_transient.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rc_render_transient.restype = C.c_int
     lib.rc_stage_count.restype = C.c_int
     lib.rc_stage_name.argtypes = [C.c_int32]
     lib.rc_stage_name.restype = C.c_char_p
@@ -187,6 +219,18 @@ def config_to_c(cfg: RenderConfig) -> rc_config:
     return c
 
 
+def transient_config_to_c(t) -> rc_transient_config:
+    c = rc_transient_config()
+    for k in ("n_bins", "bin_zero_threshold_light"):
+        setattr(c, k, int(getattr(t, k)))
+    for k in ("light_zero", "use_falloff", "use_occlusions"):
+        setattr(c, k, 1 if getattr(t, k) else 0)
+    for k in ("exposure_time", "tfilter_sigma", "transient_shift", "light_near", "indirect_scale", "rgb_max", "albedo_bias",
+              "brdf_bias", "irradiance_bias", "slf_rgb_bias"):
+        setattr(c, k, float(getattr(t, k)))
+    return c
+
+
 class RcError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"rc error {code}: {msg}")
@@ -209,6 +253,8 @@ class RadianceCache:
         if rc != 0:
             raise RcError(rc, (self.lib.rc_last_error(None) or b"").decode())
         self._keep = []
+        if cfg.transient is not None:
+            self._check(self.lib.rc_set_transient(self._h, C.byref(transient_config_to_c(cfg.transient))))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -331,6 +377,39 @@ class RadianceCache:
             if t.shape[0] != n:
                 raise ValueError(f"ray field {k} has {t.shape[0]} rows, expected {n}")
         return r, held, n
+
+    def render_transient(self, rays: Dict[str, object], randoms: Optional[Dict[str, object]] = None,
+                         outputs: Optional[Iterable[str]] = None):
+        """Time-resolved cache (rc_render_transient).  rays needs `lights` and `cam_origins` besides the usual
+        fields; randoms: {"jitter": [u0, u1, u2]} or None.  Returns dict name -> cuda tensor: [n, n_bins, 3] for the
+        histograms, [n, 3] / [n] otherwise."""
+        torch = self._torch
+        r, held, n = self._rays_struct(rays)
+        cam = self._dev(rays["cam_origins"]).reshape(-1, 3)
+        held["cam_origins"] = cam
+        rnd_p = None
+        if randoms is not None and randoms.get("jitter") is not None:
+            rnd = rc_randoms()
+            for l, j in enumerate(randoms["jitter"]):
+                if j is not None:
+                    t = self._dev(j).reshape(-1)
+                    held[f"jit{l}"] = t
+                    rnd.jitter[l] = t.data_ptr()
+            rnd_p = C.byref(rnd)
+        names = [nm for nm, _ in TRANSIENT_OUTPUTS] if outputs is None else list(outputs)
+        cout = rc_transient_outputs()
+        res = {}
+        dev = f"cuda:{self.device}"
+        nb = self.cfg.transient.n_bins
+        for nm in names:
+            kind = TRANSIENT_OUTPUTS[TRANSIENT_OUTPUT_ID[nm]][1]
+            shape = (n, nb, 3) if kind == "bins" else ((n, 3) if kind == 3 else (n,))
+            res[nm] = torch.zeros(shape, dtype=torch.float32, device=dev)
+            cout.ptr[TRANSIENT_OUTPUT_ID[nm]] = res[nm].data_ptr()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.rc_render_transient(self._h, C.byref(r), cam.data_ptr(), n, rnd_p, C.byref(cout), stream))
+        self._keep = [held]
+        return res
 
     def render_material(self, rays: Dict[str, object], randoms: Dict[str, object], num_secondary_samples: int = None):
         """Material stage (rc_render_material).  randoms: dict with the keys of

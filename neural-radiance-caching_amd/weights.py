@@ -37,6 +37,37 @@ def ide_dim(deg_view: int) -> int:
     return 2 * sum(2 ** i + 1 for i in range(deg_view))
 
 
+def _transient_shader_shapes(s, cfg: RenderConfig, sh: str, feat: int, B: int):
+    """TransientNeRFMLP (internal/nerf.py:232-414 with Config.use_transient) and its
+    TransientSurfaceLightFieldMLP (surface_light_field.py:343-403, use_lights, use_indirect) as configured by
+    transient_simulation_ngp_yobo(_cornell).gin; only what the active branch (nerf.py:691-938) with
+    use_ambient=False reads."""
+    t = cfg.transient
+    nl = 3 + 6 * t.deg_lights                      # pos_enc(lights, 0, deg_lights) + identity
+    _dense(s, f"{sh}/bottleneck_layer", feat, B)
+    _dense(s, f"{sh}/roughness_layer", feat, 1)
+    _dense(s, f"{sh}/tint_layer", feat, 3)
+    _dense(s, f"{sh}/direct_tint_layer", feat, 3)
+    _dense(s, f"{sh}/albedo_layer", feat, 3)
+    _dense(s, f"{sh}/integrated_brdf_layers_0", B + 1, cfg.ibrdf_width)
+    _dense(s, f"{sh}/integrated_brdf_layers_1", cfg.ibrdf_width, cfg.ibrdf_width)
+    _dense(s, f"{sh}/output_integrated_brdf_layer", cfg.ibrdf_width, 1)
+    _dense(s, f"{sh}/brdf_layers_0", B + 3 + 6 * t.deg_brdf, t.brdf_width)
+    _dense(s, f"{sh}/brdf_layers_1", t.brdf_width, t.brdf_width)
+    _dense(s, f"{sh}/output_brdf_layer", t.brdf_width, 1)
+    _dense(s, f"{sh}/irradiance_layers_0", feat + nl, t.irradiance_width)
+    _dense(s, f"{sh}/irradiance_layers_1", t.irradiance_width, t.irradiance_width)
+    _dense(s, f"{sh}/transient_indirect_layer", t.irradiance_width, 3 * t.n_bins)
+    s[f"{sh}/light_power"] = (1,)
+    sl = f"{sh}/SurfaceLightField"
+    in_dim = B + ide_dim(cfg.slf_deg_view) + nl
+    _dense(s, f"{sl}/layer_0", in_dim, cfg.slf_width)
+    _dense(s, f"{sl}/layer_1", cfg.slf_width, cfg.slf_width)
+    _dense(s, f"{sl}/layer_2", cfg.slf_width, cfg.slf_width)
+    _dense(s, f"{sl}/layer_bottleneck", cfg.slf_width + in_dim, cfg.slf_width)
+    _dense(s, f"{sl}/output_rgba_layer", cfg.slf_width, 3 * t.n_bins + 1)
+
+
 def param_shapes(cfg: RenderConfig, passes: Tuple[str, ...] = ("cache",)) -> "OrderedDict[str, tuple]":
     """name -> shape for every tensor the given passes read."""
     s: "OrderedDict[str, tuple]" = OrderedDict()
@@ -53,6 +84,9 @@ def param_shapes(cfg: RenderConfig, passes: Tuple[str, ...] = ("cache",)) -> "Or
     _grid(s, f"{sh}/appearance_grid", cfg.appearance_grid)
     feat = W + cfg.appearance_grid.out_dim
     B = cfg.bottleneck_width
+    if cfg.transient is not None:
+        _transient_shader_shapes(s, cfg, sh, feat, B)
+        return s
     _dense(s, f"{sh}/bottleneck_layer", feat, B)
     _dense(s, f"{sh}/roughness_layer", feat, 1)
     _dense(s, f"{sh}/tint_layer", feat, 3)
@@ -109,6 +143,8 @@ def synthetic_weights(cfg: RenderConfig, passes=("cache",), seed: int = 1, densi
         elif leaf == "kernel":
             lim = np.sqrt(6.0 / shape[0])
             a = rng.uniform(-lim, lim, size=shape)
+        elif leaf == "light_power":
+            a = np.full(shape, cfg.transient.light_power_bias)      # nerf.py:400-409 (light_init)
         else:
             a = rng.uniform(-0.1, 0.1, size=shape)
             if name.endswith("output_density_layer/bias"):

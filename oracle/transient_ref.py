@@ -1,0 +1,283 @@
+"""Time-resolved radiance cache (oracle; see oracle/__init__.py -- PARITY UNPINNED like the rest).
+
+Restates, for the resolved cornell configuration (nrc_amd.config.TransientConfig):
+  BaseNeRFMLP.predict_appearance           internal/nerf.py:561-689
+  _predict_appearance_active               internal/nerf.py:691-938
+  _compute_light_radiance                  internal/nerf.py:1097-1191
+  _compute_direct_lighting / get_brdf_light internal/nerf.py:1422-1497, 484-538
+  TransientNeRFMLP._compute_indirect_lighting / get_indirect   internal/nerf.py:1659-1797
+  TransientSurfaceLightFieldMLP.__call__   internal/surface_light_field.py:782-1069 (use_lights, n_bins outputs)
+  render_utils.zero_invalid_bins           internal/inverse_render/render_utils.py:1699-1767
+  TransientVolumeIntegrator.__call__       internal/integration.py:343-551
+  volumetric_transient_rendering, shift_direct, shift_map_coordinates   internal/render.py:250-507
+"""
+from __future__ import annotations
+
+import math as pymath
+from typing import Dict, Optional
+
+import torch
+
+from . import cache_ref, hashgrid_ref, mathx, stepfun_ref
+from .cache_ref import P, dense
+
+SH = "Cache/Shader"
+
+
+def light_enc(x, deg):
+    """coord.pos_enc(x, 0, deg, append_identity=True) (nerf.py:372-381, surface_light_field.py:228-235)."""
+    return mathx.pos_enc(x, 0, deg, append_identity=True)
+
+
+def brdf_light(weights, cfg, normals, viewdirs, lightdirs, bottleneck):
+    """get_brdf_light (nerf.py:484-538), simple_brdf=False."""
+    t = cfg.transient
+    v = -viewdirs[..., None, :]
+    h = v + lightdirs
+    halfdirs = h / torch.linalg.norm(h, dim=-1, keepdim=True)                      # math.normalize (math.py:481-483)
+    brdf_dot = mathx.dot(normals, halfdirs)
+    two = torch.cat([mathx.dot(normals, v), mathx.dot(normals, lightdirs)], dim=-1)
+    inp = torch.cat([torch.sort(two, dim=-1).values, brdf_dot], dim=-1)
+    x = torch.cat([bottleneck, light_enc(inp, t.deg_brdf)], dim=-1)
+    x = torch.relu(dense(weights, f"{SH}/brdf_layers_0", x))
+    x = torch.relu(dense(weights, f"{SH}/brdf_layers_1", x))
+    return mathx.softplus(dense(weights, f"{SH}/output_brdf_layer", x) + t.brdf_bias)
+
+
+def transient_slf_rgb(weights, cfg, rays, bottleneck, refdirs, roughness):
+    """TransientSurfaceLightFieldMLP as configured (shader bottleneck + IDE_5 + lights), main network only:
+    incoming_rgb [.., n_bins * 3] = clip(softplus(raw_rgba[:-1] + rgb_bias), 0, inf)
+    (surface_light_field.py:1011-1058)."""
+    t = cfg.transient
+    lights = rays["lights"][..., None, :] * torch.ones_like(refdirs)
+    lenc = light_enc(mathx.contract_radius(lights, cfg.contract_radius), t.deg_lights)
+    x = torch.cat([bottleneck, mathx.ide(refdirs, roughness, cfg.slf_deg_view), lenc], dim=-1)
+    x = cache_ref.slf_trunk(weights, f"{SH}/SurfaceLightField", x)
+    raw = dense(weights, f"{SH}/SurfaceLightField/output_rgba_layer", x)
+    return torch.clamp(mathx.softplus(raw[..., :-1] + t.slf_rgb_bias), min=0.0)
+
+
+def transient_indirect_diffuse(weights, cfg, rays, feature):
+    """TransientNeRFMLP.get_indirect (nerf.py:1775-1797): [feature | pos_enc(lights)] -> 64 -> 64 -> 3 n_bins."""
+    t = cfg.transient
+    lights = rays["lights"][..., None, :] * torch.ones_like(feature[..., :3])
+    x = torch.cat([feature, light_enc(lights, t.deg_lights)], dim=-1)
+    x = torch.relu(dense(weights, f"{SH}/irradiance_layers_0", x))
+    x = torch.relu(dense(weights, f"{SH}/irradiance_layers_1", x))
+    return mathx.softplus(dense(weights, f"{SH}/transient_indirect_layer", x) + t.irradiance_bias)
+
+
+def zero_invalid_bins(cfg, rays, means, diffuse, specular):
+    """render_utils.zero_invalid_bins (render_utils.py:1699-1767) on [.., n_bins, 3] histograms."""
+    t = cfg.transient
+    bins = torch.arange(t.n_bins, dtype=means.dtype).reshape((1,) * (diffuse.dim() - 2) + (t.n_bins, 1))
+    hist_light = (bins + t.bin_zero_threshold_light) * t.exposure_time
+    light_dists = torch.linalg.norm(rays["lights"][..., None, :] - means, dim=-1, keepdim=True)[..., None, :]
+    too_close = hist_light < light_dists
+    hist_cam = bins * t.exposure_time
+    max_dists = (t.n_bins - 1) * t.exposure_time
+    cam_dists = (torch.linalg.norm(rays["origins"][..., None, :] - means, dim=-1, keepdim=True)
+                 + torch.linalg.norm(rays["origins"][..., None, :] - rays["cam_origins"][..., None, :], dim=-1,
+                                     keepdim=True))[..., None, :]
+    too_far = (hist_cam + cam_dists) > max_dists
+    kill = too_close | too_far
+    if t.light_zero:
+        kill = kill | (light_dists < t.light_near)
+    z = torch.zeros_like(diffuse)
+    return torch.where(kill, z, diffuse), torch.where(kill, z, specular)
+
+
+def transient_shader(weights, cfg, rays, sres, occ=None):
+    """predict_appearance -> _predict_appearance_active for the primary pass of the cornell cache."""
+    t = cfg.transient
+    means = sres["means"]
+    viewdirs = rays["viewdirs"]
+    app = hashgrid_ref.hash_encoding(weights, f"{P}{SH}/appearance_grid", cfg.appearance_grid,
+                                     mathx.contract_radius(means, cfg.contract_radius))
+    feature = torch.cat([sres["feature"], app], dim=-1)
+    bottleneck = dense(weights, f"{SH}/bottleneck_layer", feature)
+    roughness = mathx.softplus(dense(weights, f"{SH}/roughness_layer", feature) + cfg.roughness_bias)
+    normals = sres["normals_to_use"]
+    shading_normals = normals
+
+    # lighting directions and distances (nerf.py:717-722)
+    light_offset = rays["lights"][..., None, :] - means
+    light_dists = torch.linalg.norm(light_offset, dim=-1, keepdim=True)
+    light_dirs = light_offset / torch.clamp(light_dists, min=1e-5)
+    # _compute_light_radiance: power = safe_exp(light_power), 1/d^2 falloff, light_zero
+    power = mathx.safe_exp(weights[f"{P}{SH}/light_power"].to(means.dtype))
+    light_radiance = torch.ones_like(light_dists) * power
+    if t.use_falloff:
+        light_radiance = light_radiance * (1.0 / torch.clamp(light_dists ** 2, min=1e-5))
+    if t.light_zero:
+        light_radiance = torch.where(light_dists < t.light_near, torch.zeros_like(light_radiance), light_radiance)
+    light_radiance_before_occ = light_radiance
+    light_radiance_mult = torch.ones_like(light_dists)
+
+    n_dot_l = torch.clamp(mathx.dot(shading_normals, light_dirs), min=0.0)
+    if occ is None:
+        occ = torch.zeros_like(n_dot_l).expand(n_dot_l.shape[:-1] + (3,))
+    occ = torch.where(n_dot_l <= 0.0, torch.ones_like(occ), occ)
+    light_radiance = light_radiance * (1.0 - occ)
+
+    # _compute_direct_lighting (share_material=False)
+    albedo = mathx.softplus(dense(weights, f"{SH}/albedo_layer", feature) + t.albedo_bias)
+    direct_tint = mathx.sigmoid(dense(weights, f"{SH}/direct_tint_layer", feature))
+    lb = brdf_light(weights, cfg, shading_normals, viewdirs, light_dirs, bottleneck)
+    lb = torch.where(n_dot_l == 0.0, torch.zeros_like(lb), lb)
+    direct_diffuse = torch.clamp(albedo * n_dot_l * light_radiance / pymath.pi, 0.0, t.rgb_max)
+    direct_specular = torch.clamp(direct_tint * lb * light_radiance, 0.0, t.rgb_max)
+    direct = direct_diffuse + direct_specular
+
+    # surface light field + indirect (nerf.py:795-841, 1659-1773)
+    refdirs = mathx.reflect(-viewdirs[..., None, :], normals)
+    ref_rgb = transient_slf_rgb(weights, cfg, rays, bottleneck, refdirs, roughness)        # [.., n_bins * 3]
+    dotprod = mathx.dot(normals, -viewdirs[..., None, :])
+    x = torch.cat([bottleneck, dotprod], dim=-1)
+    x = torch.relu(dense(weights, f"{SH}/integrated_brdf_layers_0", x))
+    x = torch.relu(dense(weights, f"{SH}/integrated_brdf_layers_1", x))
+    ibrdf = mathx.sigmoid(dense(weights, f"{SH}/output_integrated_brdf_layer", x) + pymath.log(3.0))
+    tint = mathx.sigmoid(dense(weights, f"{SH}/tint_layer", feature))
+    tint_exp = tint[..., None, :].expand(tint.shape[:-1] + (t.n_bins, 3)).reshape(ref_rgb.shape)
+    ti_diffuse = transient_indirect_diffuse(weights, cfg, rays, feature) * t.indirect_scale
+    ti_specular = tint_exp * ibrdf * ref_rgb * t.indirect_scale
+    shp = ti_diffuse.shape[:-1] + (t.n_bins, 3)
+    ti_diffuse, ti_specular = zero_invalid_bins(cfg, rays, means, ti_diffuse.reshape(shp), ti_specular.reshape(shp))
+    ti_diffuse = torch.clamp(ti_diffuse, 0.0, t.rgb_max)
+    ti_specular = torch.clamp(ti_specular, 0.0, t.rgb_max)
+    indirect_diffuse = ti_diffuse.sum(-2)
+    indirect_specular = ti_specular.sum(-2)
+    transient_indirect = ti_diffuse + ti_specular
+
+    # use_ambient = False (cornell.gin:33): ambient terms are exact zeros (nerf.py:847-857)
+    z = torch.zeros_like(direct)
+    indirect = indirect_diffuse + indirect_specular
+    rgb = direct + z + indirect
+    ones = torch.ones_like(rgb)
+    out = dict(
+        rgb=rgb, diffuse_rgb=direct_diffuse + indirect_diffuse + z, specular_rgb=direct_specular + indirect_specular + z,
+        ambient_rgb=z, indirect_rgb=indirect + z, albedo_rgb=albedo, occ=occ * ones, indirect_occ=ones,
+        direct_rgb=direct, indirect_diffuse_rgb=indirect_diffuse + z, direct_diffuse_rgb=direct_diffuse,
+        direct_specular_rgb=direct_specular, indirect_specular_rgb=indirect_specular + z,
+        ambient_diffuse_rgb=z, ambient_specular_rgb=z,
+        transient_indirect=transient_indirect, transient_indirect_diffuse=ti_diffuse, transient_indirect_specular=ti_specular,
+        n_dot_l_rgb=n_dot_l * ones, light_radiance_rgb=light_radiance_mult * ones,
+        irradiance_rgb=n_dot_l * light_radiance_before_occ / pymath.pi * ones,
+        ray_dists=torch.linalg.norm(rays["origins"][..., None, :] - means, dim=-1, keepdim=True),
+        light_dists=light_dists, roughness=roughness,
+    )
+    for k, v in sres.items():
+        out.setdefault(k, v)
+    return out
+
+
+def gauss_filter(sigma):
+    """render.py:411-413: taps round(-4 sigma) .. round(4 sigma), exp(-k^2 / 2 sigma^2) - exp(-8), normalised."""
+    k = torch.arange(round(-4 * sigma), round(4 * sigma) + 1, dtype=torch.float32)
+    f = torch.exp(-(k ** 2) / (2 * sigma ** 2)) - pymath.exp(-8)
+    return f / f.sum()
+
+
+def shift_direct(dists, direct_rgbs, weights, n_bins):
+    """render.py:436-477.  The scatter indexes the FLATTENED [n_rays * n_bins] histogram, so a sample whose
+    bin is >= n_bins lands in the histogram of the next ray of the batch (dropped for the last ray)."""
+    n_rays, n_samples = dists.shape
+    low = torch.clamp(torch.floor(dists), min=0.0)
+    high = torch.ceil(dists)
+    w_high = dists - low
+    w_low = 1.0 - w_high
+    base = (torch.arange(n_rays) * n_bins).repeat_interleave(n_samples)
+    idx_low = base + low.reshape(-1).to(torch.int32)
+    idx_high = base + high.reshape(-1).to(torch.int32)
+    val = (weights[..., None] * direct_rgbs).reshape(-1, 3)
+    rgb = torch.zeros(n_rays * n_bins, 3, dtype=direct_rgbs.dtype)
+    for idx, w in ((idx_low, w_low), (idx_high, w_high)):
+        ok = (idx >= 0) & (idx < n_rays * n_bins)          # jnp .at[].add drops out-of-bounds updates
+        rgb.index_add_(0, idx[ok].long(), (val * w.reshape(-1, 1))[ok])
+    return rgb.reshape(n_rays, n_bins, 3)
+
+
+def shift_map_coordinates(hist, bins_move, exposure_time, n_bins):
+    """render.py:480-496: map_coordinates(order=1, mode='constant') along the bin axis: out[y] = hist(y - d)."""
+    d = bins_move / exposure_time                                    # [N]
+    y = torch.arange(n_bins, dtype=hist.dtype)[None, :] - d[:, None]
+    i0 = torch.floor(y)
+    f = (y - i0)[..., None]
+    i0 = i0.long()
+
+    def take(i):
+        ok = (i >= 0) & (i < n_bins)
+        v = torch.gather(hist, 1, torch.clamp(i, 0, n_bins - 1)[..., None].expand(-1, -1, 3))
+        return torch.where(ok[..., None], v, torch.zeros_like(v))
+
+    return take(i0) * (1.0 - f) + take(i0 + 1) * f
+
+
+EXTRAS_ALWAYS = cache_ref.EXTRAS_ALWAYS + ("transient_indirect", "transient_indirect_specular", "transient_indirect_diffuse")
+
+
+def transient_integrate(cfg, sh):
+    """TransientVolumeIntegrator.__call__ (compute_extras=False) + volumetric_transient_rendering."""
+    t = cfg.transient
+    eps = mathx.EPS
+    w, wnf, tdist = sh["weights"], sh["weights_no_filter"], sh["tdist"]
+    acc = wnf.sum(-1)
+    r = {}
+    for k in EXTRAS_ALWAYS:
+        v = sh.get(k)
+        if v is None:
+            continue
+        r[k] = (w[..., None, None] * v).sum(-3) if v.dim() == w.dim() + 2 else (w[..., None] * v).sum(-2)
+    t_mids = 0.5 * (tdist[..., :-1] + tdist[..., 1:])
+    expect = (wnf * torch.log(t_mids)).sum(-1) / torch.clamp(acc, min=eps)
+    dm = torch.exp(expect)
+    fi = torch.finfo(dm.dtype)
+    dm = torch.nan_to_num(dm, nan=float("inf"), posinf=fi.max, neginf=fi.min)
+    r["distance_mean"] = torch.minimum(torch.maximum(dm, tdist[..., 0]), tdist[..., -1])
+    pct = stepfun_ref.weighted_percentile(tdist, wnf / torch.clamp(acc[..., None], min=eps), cfg.percentiles)
+    for i, p in enumerate(cfg.percentiles):
+        r["distance_" + ("median" if p == 50 else "percentile_" + str(int(p)))] = pct[..., i]
+
+    n_rays, n_samples = w.shape
+    dists_direct = (sh["light_dists"][..., 0] + sh["ray_dists"][..., 0]) / t.exposure_time
+    dists_indirect = sh["ray_dists"][..., 0].reshape(-1)
+    direct_rgbs = sh["direct_rgb"]
+    transient_direct = shift_direct(dists_direct + t.transient_shift / t.exposure_time, direct_rgbs, w, t.n_bins)
+    ti = sh["transient_indirect"].reshape(n_rays * n_samples, t.n_bins, 3)
+    ti = shift_map_coordinates(ti, dists_indirect + t.transient_shift, t.exposure_time, t.n_bins)
+    transient_indirect = (ti.reshape(n_rays, n_samples, t.n_bins, 3) * w[..., None, None]).sum(1)
+    r["transient_direct_no_filter"] = transient_direct
+    r["transient_indirect_no_filter"] = transient_indirect
+    if t.tfilter_sigma != 0.0:
+        f = gauss_filter(t.tfilter_sigma).to(transient_direct.dtype)
+        half = (f.numel() - 1) // 2
+        x = transient_direct.permute(0, 2, 1).reshape(n_rays * 3, 1, t.n_bins)
+        y = torch.nn.functional.conv1d(x, torch.flip(f, [0]).reshape(1, 1, -1), padding=half)   # true convolution, 'same'
+        transient_direct = y.reshape(n_rays, 3, t.n_bins).permute(0, 2, 1)
+    r["transient_direct_viz"] = transient_direct            # + dark_level (0)
+    r["transient_indirect_viz"] = transient_indirect
+    r["dists"] = dists_direct
+    r["direct_rgb_viz"] = direct_rgbs.sum(-2)
+    r["rgb"] = transient_direct + transient_indirect
+    r["acc"] = acc
+    r["direct_rgb"] = transient_direct.sum(-2)
+    r["indirect_rgb"] = transient_indirect.sum(-2)
+    r["integrated_rgb"] = r["rgb"].sum(-2)
+    r["transient_indirect"] = transient_indirect
+    r["transient_direct"] = transient_direct
+    return r
+
+
+def transient_forward(weights, cfg, rays: Dict[str, torch.Tensor], jitters=None, want_grad_normals=False):
+    """TransientNeRFModel.__call__ (BaseNeRFModel.__call__, models.py:657-774) for primary rays: sampler ->
+    (no resampling, TransientNeRFModel.resample_render=False) -> TransientNeRFMLP -> TransientVolumeIntegrator."""
+    t = cfg.transient
+    if t.use_occlusions:
+        # _compute_occlusions (nerf.py:1193-1342, shadow rays through the cache with weights_only=True; forced on
+        # by the Trainer in vis_only mode) is not restated yet: the training gin renders with occ = 0.
+        raise NotImplementedError("transient occlusions (shadow rays) are not part of the oracle yet")
+    history = cache_ref.proposal_sampler(weights, cfg, rays, jitters, False, False, want_grad_normals)
+    filtered, inds = cache_ref.maybe_resample(cfg, history[-1], False)
+    sh = transient_shader(weights, cfg, rays, filtered, None)
+    integ = transient_integrate(cfg, sh)
+    return {"sampler": history, "shader": sh, "integrator": integ, "render": integ}

@@ -68,3 +68,18 @@ def secondary_case(n, seed=5):
     rnd = {"jitter": [rng.uniform(size=(n,)).astype(np.float32) for _ in range(3)],
            "gumbel": rng.gumbel(size=(n, 32)).astype(np.float32)}
     return rays, rnd
+
+
+@functools.lru_cache(maxsize=2)
+def weights_transient_np(smooth=False):
+    kw = dict(level_decay=0.5, table_range=0.2) if smooth else {}
+    return nrc_amd.synthetic_weights(nrc_amd.cornell_transient_config(), **kw)
+
+
+def oracle_transient(n_rays, jitter_seed=None, seed=20200823, smooth=False, dtype=torch.float32):
+    """Time-resolved cornell cache on synthetic transient rays (oracle/transient_ref.py)."""
+    from oracle import transient_ref
+    cfg = nrc_amd.cornell_transient_config()
+    rays = nrc_amd.synthetic_transient_rays(n_rays, seed=seed)
+    jit = None if jitter_seed is None else [torch.from_numpy(j) for j in jitters(n_rays, seed=jitter_seed)]
+    return transient_ref.transient_forward(to_torch(weights_transient_np(smooth), dtype), cfg, rays_torch(rays, dtype), jit)

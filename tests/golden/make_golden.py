@@ -74,7 +74,24 @@ def operator_cases():
     print("operators.npz", list(d.keys()))
 
 
+def transient_case(n_rays, jitter_seed, name):
+    """Time-resolved cornell cache (oracle/transient_ref.py) in float64; only the render dict is stored."""
+    out = common.oracle_transient(n_rays, jitter_seed=jitter_seed, dtype=F64)
+    d = {"render_" + k: v.numpy().astype(np.float32) for k, v in out["render"].items()
+         if k not in ("transient_direct", "transient_indirect", "transient_direct_no_filter", "transient_indirect_no_filter",
+                      "weights", "dists")}
+    d["meta"] = np.array([n_rays, -1 if jitter_seed is None else jitter_seed], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, name), **d)
+    print(name, sorted(d.keys())[:6], "...")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "transient":       # only the transient fixtures
+        transient_case(16, None, "transient_16_det.npz")
+        transient_case(16, 5, "transient_16_jit.npz")
+        sys.exit(0)
+    transient_case(16, None, "transient_16_det.npz")
+    transient_case(16, 5, "transient_16_jit.npz")
     cache_case(256, None, 0.0, "hotdog_cache_256_det.npz")
     cache_case(256, 7, 0.0, "hotdog_cache_256_jit.npz")
     cache_case(64, 11, 4.0, "hotdog_cache_64_shell.npz")
