@@ -31,15 +31,17 @@ RAYS_PER_BATCH = 1024
 GRID_BYTES = {"grid0": 64 * 192, "grid1": 64 * 224, "grid2": 32 * 1024, "grid_app": 32 * 1024}   # per ray
 SHADER_FLOP_PER_SAMPLE = 253824          # output-relevant (heads + IBRDF + SurfaceLightField MLP)
 SHADED_SAMPLES = 32
-# density MLPs (geometry.py:123-153, 2 x 64 + output heads) per sample of each proposal level, and the
-# backward pass of the last one for the analytic normals (geometry.py:421-460)
-DENSITY_FLOP_PER_SAMPLE = (2 * (6 * 64 + 64 * 64 + 64), 2 * (7 * 64 + 64 * 64 + 64), 2 * (32 * 64 + 64 * 64 + 4 * 64))
-NORMALS_BWD_FLOP_PER_SAMPLE = 2 * (64 + 64 * 64 + 64 * 32)
+# SURVEY.md §8(d) figure of record per primary ray, cache-only: 64 x 9 088 + 64 x 9 216 + 32 x 12 800 (density MLPs of
+# the three proposal levels) + 32 x 253 824 (shader) = 9 703 424 FLOP.  The backward pass for the analytic normals
+# that the fused kernel also runs (32 x 12 416 FLOP) is NOT counted.
+DENSITY_FLOP_PER_SAMPLE = (9088, 9216, 12800)
 SAMPLES = (64, 64, 32)
-FUSED_FLOP_PER_RAY = (sum(s * f for s, f in zip(SAMPLES, DENSITY_FLOP_PER_SAMPLE))
-                      + SHADED_SAMPLES * (SHADER_FLOP_PER_SAMPLE + NORMALS_BWD_FLOP_PER_SAMPLE))
+FUSED_FLOP_PER_RAY = sum(s * f for s, f in zip(SAMPLES, DENSITY_FLOP_PER_SAMPLE)) + SHADED_SAMPLES * SHADER_FLOP_PER_SAMPLE
+assert FUSED_FLOP_PER_RAY == 9703424
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
+# per-launch FETCH_SIZE + WRITE_SIZE (KiB) of the dominant kernel, profiles/r01_pmc_summary.txt
+PMC_KIB = {"fused": 150880.0 + 248.0, "shader": 8933.5 + 1920.0}
 
 
 def cpu_baseline(cfg, weights_np, n_rays, budget_s=20.0):
@@ -69,12 +71,45 @@ def cpu_baseline(cfg, weights_np, n_rays, budget_s=20.0):
                       f"incl. the reference's dead cache-EnvMap MLP and autograd normals; median {med*1e3:.0f} ms"}
 
 
+def transient_line(local_rank, dev, n_rays=1024, steps=20, warmup=3):
+    """Secondary measurement (not part of `value`): rc_render_transient on 1024 synthetic cornell rays,
+    700 bins x 3 channels per ray out of two MFMA kernels (BASELINE configs[4])."""
+    import numpy as np
+    import torch
+
+    import nrc_amd
+    from nrc_amd import rc_ext
+
+    cfg = nrc_amd.cornell_transient_config()
+    rc = rc_ext.RadianceCache(cfg, local_rank)
+    rc.load_weights(nrc_amd.synthetic_weights(cfg))
+    rays = nrc_amd.synthetic_transient_rays(n_rays)
+    f = {k: torch.from_numpy(np.asarray(v)).to(dev).contiguous() for k, v in rays.hot_fields().items()}
+    keys = ["rgb", "integrated_rgb", "acc", "transient_direct_viz", "transient_indirect_viz"]
+    for _ in range(warmup):
+        rc.render_transient(f, None, outputs=keys)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rc.render_transient(f, None, outputs=keys)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    # algorithmic FLOP of the two wide heads alone: 32 samples x 2 x (128 x 2101 + 64 x 2100) per ray
+    head_flop = n_rays * 32 * 2 * (128 * 2101 + 64 * 2100)
+    return {"workload": "cornell time-resolved cache, 1024 rays x (64,64,32) samples x 700 bins (configs[4])",
+            "rays_per_s": n_rays / (ms * 1e-3), "ms_per_step": ms, "steps": steps,
+            "wide_heads_gflop_per_step": head_flop / 1e9,
+            "note": "output allocation (3 x [1024,700,3] fp32 zero-fills) is inside the step"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-transient", action="store_true",
+                    help="skip the secondary measurement of the time-resolved cache (configs[4])")
     ap.add_argument("--graph-mode", type=int, default=2, help="0 eager, 1 lazy hipGraph, 2 hipGraph at once")
     ap.add_argument("--plan", choices=("fused", "staged"), default="fused",
                     help="fused: one launch per batch (rc_set_fused 1, default); staged: one launch per stage")
@@ -193,9 +228,10 @@ def main():
                    "kernel_plan": "fused: 1 launch per batch, 1 wavefront per ray" if fused else "staged: 13 launches per batch"},
         "roofline": {"kernel": "k_cache_fused" if fused else "k_cache_shader", "bound": "mfma", "achieved": achieved_tf,
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
-                     # HBM-side bytes per launch from the rocprofv3 PMC passes kept under profiles/
-                     # (FETCH_SIZE 8933.5 KiB uncorrected + WRITE_SIZE 1920 KiB); not re-measured here
-                     "traffic": (8933.5 + 1920.0) * 1024, "traffic_source": "profiles/r01_pmc_summary.txt",
+                     # HBM-side bytes per launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE +
+                     # WRITE_SIZE in KiB, uncorrected: random 4/16-byte gathers); not re-measured here
+                     "traffic": (PMC_KIB["fused"] if fused else PMC_KIB["shader"]) * 1024,
+                     "traffic_source": "profiles/r01_pmc_summary.txt",
                      "avg_launch_ms": sh_ms,
                      "algorithmic_flop_per_launch": flops},
         "hashgrid": {"kernels": "k_hashgrid_fwd x4 (grid0, grid1, grid2, grid_app)", "bound": "hbm",
@@ -203,6 +239,8 @@ def main():
                      "sum_launch_ms": grid_ms, "algorithmic_bytes_per_batch": grid_bytes},
         "stage_ms_separate_pass_staged_plan": stage,
     }
+    if not args.no_transient and world == 1:
+        res["transient"] = transient_line(local_rank, dev)
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline(cfg, weights, RAYS_PER_BATCH)
     else:

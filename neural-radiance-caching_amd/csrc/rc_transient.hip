@@ -288,6 +288,14 @@ constexpr int kBinFrags = kTilesB * kFragsPerTile;
 constexpr int kSP = 8;                           // per-sample parameters kept in LDS
 constexpr int kWaveLds = 2 * kHist + kSP * 32 + 6 * 32;   // floats: indirect hist, direct hist, params, bin sums
 
+// softplus on the hardware transcendentals (v_exp_f32 / v_log_f32, about 1 ulp each): the per-bin heads evaluate
+// 2 x 2100 of them per sample, which is what bounds k_transient_bins.  log1p(e) for small e by its series.
+__device__ __forceinline__ float softplus_hw(float x) {
+  const float e = __expf(-fabsf(x));
+  const float l = e < 1.0e-3f ? e * (1.0f - 0.5f * e) : __logf(1.0f + e);
+  return fmaxf(x, 0.0f) + l;
+}
+
 __device__ __forceinline__ void ws_issue_rt(const WStream& w, int c, int nf) {
 #pragma unroll
   for (int k = 0; k < kChunk / 4 / kWaves; ++k) {
@@ -401,8 +409,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
         const float w = sp[P_W * 32 + i];
         // nerf.py:1795-1797 and :1712-1719: softplus(. + irradiance_bias) * indirect_scale;
         // surface_light_field.py:1037-1058 and nerf.py:1721-1723: tint * ibrdf * clip(softplus(. + rgb_bias), 0) * scale
-        float diff = softplus(ai[r] + a.irradiance_bias) * a.indirect_scale;
-        const float ref = fmaxf(softplus(1.0f * as[r] + a.slf_rgb_bias), 0.0f);
+        float diff = softplus_hw(ai[r] + a.irradiance_bias) * a.indirect_scale;
+        const float ref = fmaxf(softplus_hw(1.0f * as[r] + a.slf_rgb_bias), 0.0f);
         const float tib = c == 0 ? sp[P_TIB0 * 32 + i] : (c == 1 ? sp[P_TIB1 * 32 + i] : sp[P_TIB2 * 32 + i]);
         float spec = (tib * ref) * a.indirect_scale;
         // zero_invalid_bins (render_utils.py:1699-1767)
