@@ -280,8 +280,13 @@ typedef struct rc_transient_config {
   float brdf_bias;                  /* BaseNeRFMLP.brdf_bias                                            */
   float irradiance_bias;            /* TransientNeRFMLP.irradiance_bias                                 */
   float slf_rgb_bias;               /* TransientSurfaceLightFieldMLP.rgb_bias                           */
-  int32_t use_occlusions;           /* must be 0 this round (shadow rays: RC_ERR_UNSUPPORTED)           */
-  int32_t reserved[9];
+  int32_t use_occlusions;           /* Config.use_occlusions for every ray (the Trainer's vis_only override,
+                                       engine/trainer.py:198-202): one weights-only shadow ray per shaded
+                                       sample through the cache (internal/nerf.py:1193-1342)              */
+  float occ_threshold;              /* Config.occ_threshold_min (== _max)                               */
+  float shadow_near;                /* Config.shadow_near_min (== _max)                                 */
+  float shadow_far;                 /* Config.secondary_far                                             */
+  int32_t reserved[6];
 } rc_transient_config;
 
 /* Switches a freshly created handle to the transient model: rc_load_weights then expects the
@@ -312,9 +317,10 @@ typedef struct rc_transient_outputs { float* ptr[RC_TOUT_COUNT]; } rc_transient_
 
 /* rays->lights is required; cam_origins [n,3] is the camera centre of each ray (Rays.cam_origins,
  * internal/inverse_render/render_utils.py:1733-1740).  Direct-light bins beyond n_bins spill into the
- * next ray of THIS call's batch exactly as the reference's flattened scatter does (internal/render.py:447-475). */
+ * next ray of THIS call's batch exactly as the reference's flattened scatter does (internal/render.py:447-475).
+ * shadow_rnd (use_occlusions only): per-level jitter of the n * 32 shadow rays, NULL = deterministic branch. */
 int rc_render_transient(rc_handle* h, const rc_rays* rays, const float* cam_origins, int64_t n, const rc_randoms* rnd,
-                        const rc_transient_outputs* out, void* stream);
+                        const rc_randoms* shadow_rnd, const rc_transient_outputs* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -83,7 +83,6 @@ class TransientConfig:
     use_occlusions: bool = False
     occ_threshold: float = 0.9        # cornell.gin:167-168 (min == max)
     shadow_near: float = 0.1          # cornell.gin:172-173 (min == max)
-    shadow_normal_eps_dot_min: float = 0.1   # cornell.gin:176
     shadow_far: float = 1.0           # Config.secondary_far, cornell.gin:33
 
 
@@ -174,6 +173,10 @@ def cornell_transient_config(**overrides) -> RenderConfig:
         appearance_grid=g(2048, 4),                              # transient_ngp_yobo.gin:175-180
         contract_radius=5.0,
         rgb_max=100.0,
+        # shadow rays (secondary-ray sampler): cornell.gin:176, :179 (secondary_normal_eps), configs.py:498
+        shadow_normal_eps_dot_min=0.1,
+        secondary_normal_eps=0.0,
+        env_map_distance=3.0e38,          # Config.env_map_distance = inf: no far clamp on secondary rays
         transient=dataclasses.replace(TransientConfig(), **t_over),
     )
     return dataclasses.replace(base, **overrides)

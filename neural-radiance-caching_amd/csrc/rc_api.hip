@@ -582,7 +582,7 @@ int ensure_workspace(rc_handle* h, int64_t n) {
   if ((rc = ws_alloc(h, "inds", n))) return rc;
   if ((rc = ws_alloc(h, "src_idx", n))) return rc;
   if ((rc = ws_alloc(h, "filt_weight", n))) return rc;
-  if (h->transient) {
+  if (h->transient && h->ws_prefix.empty()) {
     const int64_t tiles = (np + 31) / 32;
     if ((rc = ws_alloc(h, "t_irr", tiles * 32 * 64))) return rc;
     if ((rc = ws_alloc(h, "t_slf", tiles * 64 * 64))) return rc;
@@ -866,6 +866,7 @@ namespace {
 struct RenderArgs {
   rc_rays rays; rc_randoms rnd; bool have_rnd; int64_t n; uint32_t mask; rc_outputs out; int slot; bool fused;
   const rc_transient_outputs* tout = nullptr; const float* cam_origins = nullptr;
+  const rc_randoms* shadow_rnd = nullptr; bool weights_only = false; bool force_grad = false;
 };
 
 void enqueue_transient_tail(rc_handle* h, const RenderArgs& A, hipStream_t st);
@@ -917,13 +918,14 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     sa.sdist = W(h, "sdist" + L); sa.tdist = W(h, "tdist" + L); sa.means = W(h, "means" + L);
     sa.anneal = c.anneal; sa.padding = c.resample_padding;
     sa.secondary = secondary ? 1 : 0;
+    sa.use_raydist = (secondary || h->transient) ? 1 : 0;     // TransientNeRFModel: use_raydist_for_secondary_only = False
     sa.raydist_p = c.raydist_p; sa.raydist_premult = c.raydist_premult;
     sa.eps_dot_min = c.shadow_normal_eps_dot_min; sa.far_clamp = c.env_map_distance;
     stage_mark(h, slot, ST_SAMPLE0 + 3 * l, st);
     rc_launch_sample(sa, st);
 
     stage_mark(h, slot, ST_GRID0 + 3 * l, st);
-    const bool want_grad = (l == NL - 1) && A.out.ptr[RC_OUT_NORMALS] != nullptr;
+    const bool want_grad = (l == NL - 1) && (A.out.ptr[RC_OUT_NORMALS] != nullptr || A.force_grad);
     rc_launch_hashgrid(h->grids[l].dev, W(h, "means" + L), 1, np, W(h, "feat" + L), 1, np, c.contract_radius,
                        want_grad ? W(h, "jac") : nullptr, st);
 
@@ -945,6 +947,19 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
   const std::string LL = std::to_string(NL - 1);
   const int S2 = c.num_samples[NL - 1];
   const int64_t np2 = n * S2;
+  if (A.weights_only) {
+    // weights_only=True (models.py:944-982): no shader; only acc = sum of the last level's weights is consumed
+    RcCompositeArgs ca{};
+    ca.directions = rays->directions; ca.origins = rays->origins; ca.lights = rays->lights; ca.n_rays = n; ca.S = S2;
+    ca.tdist = W(h, "tdist" + LL); ca.density = W(h, "density" + LL); ca.means = W(h, "means" + LL);
+    ca.normals_pred = W(h, "normals_pred"); ca.normals_grad = nullptr;
+    ca.shade = W(h, "shade"); ca.Sf = S2; ca.weights = W(h, "weights" + LL);
+    ca.bg = 0.0f;
+    ca.pct[0] = c.percentiles[0]; ca.pct[1] = c.percentiles[1]; ca.pct[2] = c.percentiles[2];
+    ca.out = A.out;
+    rc_launch_composite(ca, st);
+    return;
+  }
   stage_mark(h, slot, ST_RESAMPLE, st);
   const int32_t* src = nullptr;
   if (resample) {

@@ -61,7 +61,8 @@ struct RcSampleArgs {
   float* means;               // SoA [3][n*S]
   // constants
   float anneal, padding;
-  int32_t secondary;          // power-ladder warp + near replacement
+  int32_t secondary;          // near replacement from the surface normal + far clamp (secondary rays)
+  int32_t use_raydist;        // sample in power-ladder distance (Model.get_bg_and_raydist, models.py:183-191)
   float raydist_p, raydist_premult, eps_dot_min, far_clamp;
 };
 void rc_launch_sample(const RcSampleArgs& a, hipStream_t stream);
@@ -242,7 +243,8 @@ struct RcTransShaderArgs {
   int64_t n; int32_t samples_per_ray;
   const float* hbuf; const float* app; const float* means; const float* normals;   // means / normals: SoA [3][n]
   const float* origins; const float* viewdirs; const float* lights; const float* cam_origins;   // per ray [.,3]
-  const float* occ;                        // optional per-sample occlusion [n]
+  const float* occ;                        // optional: acc of the shadow ray of each sample [n] (nerf.py:1300-1340)
+  float occ_threshold;
   const float* wstream; const float* ide_coef;
   float roughness_bias, albedo_bias, brdf_bias, rgb_max, contract_radius;
   float light_power, light_near; int32_t use_falloff, light_zero;
@@ -265,6 +267,14 @@ struct RcTransBinsArgs {
   float* out_irradiance_rgb; float* out_light_radiance_rgb; float* out_n_dot_l_rgb; float* out_direct_diffuse_rgb;
   float* out_direct_specular_rgb; float* out_indirect_diffuse_rgb; float* out_indirect_specular_rgb; float* out_direct_rgb_viz;
 };
+struct RcShadowRayArgs {
+  int64_t n; int32_t samples_per_ray;      // n = shaded samples
+  const float* means; const float* normals;            // SoA [3][n]
+  const float* lights;                                 // per primary ray [.,3]
+  float normal_eps, shadow_near, shadow_far, light_near;
+  float* origins; float* dirs; float* near; float* far; float* out_normals; float* out_lights;   // AoS [n,3] / [n]
+};
+void rc_launch_shadow_rays(const RcShadowRayArgs& a, hipStream_t stream);
 int rc_transient_shader_frags();
 int rc_transient_bins_frags();
 void rc_launch_transient_shader(const RcTransShaderArgs& a, hipStream_t stream);

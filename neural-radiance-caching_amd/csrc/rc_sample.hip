@@ -68,14 +68,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_sample_level(RcSampleAr
 
   // --- s -> t (coord.py:259-260), cast (render.py:49-59, 106-131)
   float s_near = 0.0f, s_far = 0.0f;
-  if (a.secondary) {
+  if (a.use_raydist) {
     s_near = power_ladder(near, a.raydist_p, a.raydist_premult);
     s_far = power_ladder(far, a.raydist_p, a.raydist_premult);
   }
   for (int e2 = lane; e2 <= S; e2 += 64) {
     const float s = s_out[e2];
     float t;
-    if (a.secondary) t = inv_power_ladder(s * s_far + (1.0f - s) * s_near, a.raydist_p, a.raydist_premult, y_max);
+    if (a.use_raydist) t = inv_power_ladder(s * s_far + (1.0f - s) * s_near, a.raydist_p, a.raydist_premult, y_max);
     else t = s * far + (1.0f - s) * near;
     s_v[e2] = t;
     if (ray_ok) {

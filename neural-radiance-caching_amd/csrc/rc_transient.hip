@@ -142,7 +142,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_shader(RcTransShaderA
   if (a.light_zero && ldist < a.light_near) radiance = 0.0f;
   const float radiance_before_occ = radiance;
   const float n_dot_l = fmaxf(0.0f, nx * ldx + ny * ldy + nz * ldz);          // nerf.py:744
-  float occ = a.occ ? a.occ[pc] : 0.0f;
+  float occ = 0.0f;
+  if (a.occ) {
+    // nerf.py:1300-1340: acc of the shadow ray; no occlusion when the light sits on the camera; thresholded
+    occ = a.occ[pc];
+    const float bx = lx - ox, by = ly - oy, bz = lz - oz;
+    if (sqrtf(bx * bx + by * by + bz * bz) < 1e-3f) occ = 0.0f;
+    if (occ <= a.occ_threshold) occ = 0.0f;
+  }
   if (n_dot_l <= 0.0f) occ = 1.0f;                                            // nerf.py:764
   radiance = radiance * (1.0f - occ);
   const float dotp = nx * (-vx) + ny * (-vy) + nz * (-vz);
@@ -275,6 +282,26 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_shader(RcTransShaderA
     o[RC_TS_RDIST * n] = rdist;
     o[RC_TS_CAMDIST * n] = camdist;
   }
+}
+
+// Shadow rays of _compute_occlusions (nerf.py:1233-1288; get_secondary_rays with the ActiveSampler,
+// render_utils.py:462-478, 927-1056): one ray per shaded sample towards the light.
+__global__ void k_shadow_rays(RcShadowRayArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.n) return;
+  const int64_t ray = p / a.samples_per_ray;
+  const float mx = a.means[p], my = a.means[a.n + p], mz = a.means[2 * a.n + p];
+  const float nx = a.normals[p], ny = a.normals[a.n + p], nz = a.normals[2 * a.n + p];
+  const float lx = a.lights[3 * ray], ly = a.lights[3 * ray + 1], lz = a.lights[3 * ray + 2];
+  const float ox = lx - mx, oy = ly - my, oz = lz - mz;
+  const float dist = sqrtf(ox * ox + oy * oy + oz * oz);
+  const float dn = fmaxf(dist, 1e-5f);
+  a.origins[3 * p] = mx + nx * a.normal_eps; a.origins[3 * p + 1] = my + ny * a.normal_eps; a.origins[3 * p + 2] = mz + nz * a.normal_eps;
+  a.dirs[3 * p] = ox / dn; a.dirs[3 * p + 1] = oy / dn; a.dirs[3 * p + 2] = oz / dn;
+  a.near[p] = a.shadow_near;
+  a.far[p] = fminf(fmaxf(dist - a.light_near, a.shadow_near), a.shadow_far);       // nerf.py:1276-1281
+  a.out_normals[3 * p] = nx; a.out_normals[3 * p + 1] = ny; a.out_normals[3 * p + 2] = nz;
+  a.out_lights[3 * p] = lx; a.out_lights[3 * p + 1] = ly; a.out_lights[3 * p + 2] = lz;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -434,9 +461,13 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
           const float wt = ((int)i0 == b ? 1.0f - fw : 0.0f) + ((int)i0 + 1 == b ? fw : 0.0f);
           const bool ok = fok && y >= 0 && y < kBins;
           // the two half-waves work on different samples and may meet in one entry: one after the other
-          // (within a half-wave the 32 lanes hold 32 different entries of ONE sample: plain read-add-write)
-          if (ok && h == 0) hist_i[y * 3 + c] = hist_i[y * 3 + c] + val * wt;
-          if (ok && h == 1) hist_i[y * 3 + c] = hist_i[y * 3 + c] + val * wt;
+          // (within a half-wave the 32 lanes hold 32 different entries of ONE sample: plain read-add-write; the
+          // wave barrier keeps the compiler from merging the two phases into one colliding instruction)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            if (ok && h == hh) hist_i[y * 3 + c] = hist_i[y * 3 + c] + val * wt;
+            __builtin_amdgcn_wave_barrier();
+          }
         }
       }
       cd += __shfl_xor(cd, 32, 64);
@@ -603,6 +634,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
 }
 
 }  // namespace
+
+void rc_launch_shadow_rays(const RcShadowRayArgs& a, hipStream_t stream) {
+  if (a.n <= 0) return;
+  hipLaunchKernelGGL(k_shadow_rays, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, stream, a);
+}
 
 int rc_transient_shader_frags() { return TFrags::COUNT; }
 int rc_transient_bins_frags() { return kBinFrags; }

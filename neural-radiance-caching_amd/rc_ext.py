@@ -101,7 +101,8 @@ class rc_transient_config(C.Structure):
                 ("light_zero", C.c_int32), ("use_falloff", C.c_int32), ("indirect_scale", C.c_float),
                 ("rgb_max", C.c_float), ("albedo_bias", C.c_float), ("brdf_bias", C.c_float),
                 ("irradiance_bias", C.c_float), ("slf_rgb_bias", C.c_float), ("use_occlusions", C.c_int32),
-                ("reserved", C.c_int32 * 9)]
+                ("occ_threshold", C.c_float), ("shadow_near", C.c_float), ("shadow_far", C.c_float),
+                ("reserved", C.c_int32 * 6)]
 
 
 # rc_transient_output_id -> (name, trailing shape); order must match include/rc_abi.h
@@ -178,7 +179,8 @@ def load_library():
     lib.rc_set_fused.restype = C.c_int
     lib.rc_set_transient.argtypes = [C.c_void_p, C.c_void_p]
     lib.rc_set_transient.restype = C.c_int
-    lib.rc_render_transient.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rc_render_transient.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]
     lib.rc_render_transient.restype = C.c_int
     lib.rc_stage_count.restype = C.c_int
     lib.rc_stage_name.argtypes = [C.c_int32]
@@ -226,7 +228,7 @@ def transient_config_to_c(t) -> rc_transient_config:
     for k in ("light_zero", "use_falloff", "use_occlusions"):
         setattr(c, k, 1 if getattr(t, k) else 0)
     for k in ("exposure_time", "tfilter_sigma", "transient_shift", "light_near", "indirect_scale", "rgb_max", "albedo_bias",
-              "brdf_bias", "irradiance_bias", "slf_rgb_bias"):
+              "brdf_bias", "irradiance_bias", "slf_rgb_bias", "occ_threshold", "shadow_near", "shadow_far"):
         setattr(c, k, float(getattr(t, k)))
     return c
 
@@ -381,21 +383,27 @@ class RadianceCache:
     def render_transient(self, rays: Dict[str, object], randoms: Optional[Dict[str, object]] = None,
                          outputs: Optional[Iterable[str]] = None):
         """Time-resolved cache (rc_render_transient).  rays needs `lights` and `cam_origins` besides the usual
-        fields; randoms: {"jitter": [u0, u1, u2]} or None.  Returns dict name -> cuda tensor: [n, n_bins, 3] for the
+        fields; randoms: {"jitter": [u0, u1, u2], "shadow_jitter": [v0, v1, v2]} or None (shadow_jitter: per-level jitter of
+        the n * 32 shadow rays when the config has use_occlusions).  Returns dict name -> cuda tensor: [n, n_bins, 3] for the
         histograms, [n, 3] / [n] otherwise."""
         torch = self._torch
         r, held, n = self._rays_struct(rays)
         cam = self._dev(rays["cam_origins"]).reshape(-1, 3)
         held["cam_origins"] = cam
-        rnd_p = None
-        if randoms is not None and randoms.get("jitter") is not None:
+        def jitter_struct(key):
+            if randoms is None or randoms.get(key) is None:
+                return None
             rnd = rc_randoms()
-            for l, j in enumerate(randoms["jitter"]):
+            for l, j in enumerate(randoms[key]):
                 if j is not None:
                     t = self._dev(j).reshape(-1)
-                    held[f"jit{l}"] = t
+                    held[f"{key}{l}"] = t
                     rnd.jitter[l] = t.data_ptr()
-            rnd_p = C.byref(rnd)
+            held[key + "_struct"] = rnd
+            return C.byref(rnd)
+
+        rnd_p = jitter_struct("jitter")
+        shadow_p = jitter_struct("shadow_jitter")      # [3][n * 32], use_occlusions only
         names = [nm for nm, _ in TRANSIENT_OUTPUTS] if outputs is None else list(outputs)
         cout = rc_transient_outputs()
         res = {}
@@ -407,7 +415,7 @@ class RadianceCache:
             res[nm] = torch.zeros(shape, dtype=torch.float32, device=dev)
             cout.ptr[TRANSIENT_OUTPUT_ID[nm]] = res[nm].data_ptr()
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        self._check(self.lib.rc_render_transient(self._h, C.byref(r), cam.data_ptr(), n, rnd_p, C.byref(cout), stream))
+        self._check(self.lib.rc_render_transient(self._h, C.byref(r), cam.data_ptr(), n, rnd_p, shadow_p, C.byref(cout), stream))
         self._keep = [held]
         return res
 

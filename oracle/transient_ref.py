@@ -5,6 +5,7 @@ Restates, for the resolved cornell configuration (nrc_am
   _predict_appearance_active               internal/nerf.py:691-938
   _compute_light_radiance                  internal/nerf.py:1097-1191
   _compute_direct_lighting / get_brdf_light internal/nerf.py:1422-1497, 484-538
+  _compute_occlusions (shadow rays)        internal/nerf.py:1193-1342, render_utils.py:462-478, 927-1056
   TransientNeRFMLP._compute_indirect_lighting / get_indirect   internal/nerf.py:1659-1797
   TransientSurfaceLightFieldMLP.__call__   internal/surface_light_field.py:782-1069 (use_lights, n_bins outputs)
   render_utils.zero_invalid_bins           internal/inverse_render/render_utils.py:1699-1767
@@ -268,16 +269,50 @@ def transient_integrate(cfg, sh):
     return r
 
 
-def transient_forward(weights, cfg, rays: Dict[str, torch.Tensor], jitters=None, want_grad_normals=False):
-    """TransientNeRFModel.__call__ (BaseNeRFModel.__call__, models.py:657-774) for primary rays: sampler ->
-    (no resampling, TransientNeRFModel.resample_render=False) -> TransientNeRFMLP -> TransientVolumeIntegrator."""
+def shadow_occlusion(weights, cfg, rays, sres, shadow_jitters=None):
+    """_compute_occlusions (nerf.py:1193-1342): one shadow ray per shaded sample towards the light, traced through
+    the cache with is_secondary=True, weights_only=True; occ = acc, zeroed at or below occ_threshold.
+
+    get_secondary_rays(num_secondary_samples=1, samplers=((ActiveSampler(), 1.0),), offset_origins=False,
+    normal_eps=secondary_normal_eps, refdir_eps=shadow_near, far=secondary_far) (render_utils.py:927-1056):
+    origin = mean + normal * normal_eps, direction = (light - mean) / max(|.|, 1e-5) (ActiveSampler,
+    render_utils.py:462-478; the round trip through the shading frame is the identity), near = shadow_near;
+    then far = clip(|light - mean| - light_near, near, secondary_far) and the rays carry the sample normals
+    (Config.shadow_normals_target = 'normals', the analytic ones), which move `near` to
+    shadow_normal_eps_dot_min / (n . d) in the secondary-ray sampler (sampling.py:182-205)."""
     t = cfg.transient
-    if t.use_occlusions:
-        # _compute_occlusions (nerf.py:1193-1342, shadow rays through the cache with weights_only=True; forced on
-        # by the Trainer in vis_only mode) is not restated yet: the training gin renders with occ = 0.
-        raise NotImplementedError("transient occlusions (shadow rays) are not part of the oracle yet")
-    history = cache_ref.proposal_sampler(weights, cfg, rays, jitters, False, False, want_grad_normals)
+    means = sres["means"]
+    n, s, _ = means.shape
+    normals = sres["normals"]
+    off = rays["lights"][..., None, :] - means
+    dist = torch.linalg.norm(off, dim=-1, keepdim=True)
+    dirs = off / torch.clamp(dist, min=1e-5)
+    near = torch.full((n * s, 1), t.shadow_near, dtype=means.dtype)
+    far = torch.full((n * s, 1), t.shadow_far, dtype=means.dtype)
+    far = torch.minimum(torch.maximum(dist.reshape(-1, 1) - t.light_near, near), far)
+    srays = dict(origins=(means + normals * cfg.secondary_normal_eps).reshape(-1, 3), directions=dirs.reshape(-1, 3),
+                 viewdirs=dirs.reshape(-1, 3), near=near, far=far, normals=normals.reshape(-1, 3),
+                 lights=rays["lights"][..., None, :].expand(n, s, 3).reshape(-1, 3),
+                 lossmult=torch.ones(n * s, 1, dtype=means.dtype))
+    srays["far"] = torch.clamp(srays["far"], max=cfg.env_map_distance)                      # models.py:670-673
+    hist = cache_ref.proposal_sampler(weights, cfg, srays, shadow_jitters, True, True, False)
+    acc = hist[-1]["weights"].sum(-1).reshape(n, s, 1)
+    occ = acc.expand(n, s, 3)
+    base = torch.linalg.norm(rays["lights"] - rays["origins"], dim=-1)[:, None, None]
+    occ = torch.where(base < 1e-3, torch.zeros_like(occ), occ)
+    return torch.where(occ <= t.occ_threshold, torch.zeros_like(occ), occ), acc[..., 0]
+
+
+def transient_forward(weights, cfg, rays: Dict[str, torch.Tensor], jitters=None, shadow_jitters=None,
+                      want_grad_normals=False):
+    """TransientNeRFModel.__call__ (BaseNeRFModel.__call__, models.py:657-774) for primary rays: sampler ->
+    (no resampling, TransientNeRFModel.resample_render=False) -> TransientNeRFMLP -> TransientVolumeIntegrator.
+    TransientNeRFModel keeps Model.use_raydist_for_secondary_only = False (models.py:122; the gin files only
+    bind NeRFModel's), so primary rays are sampled in power-ladder distance too (models.py:183-191)."""
+    t = cfg.transient
+    history = cache_ref.proposal_sampler(weights, cfg, rays, jitters, False, True, want_grad_normals or t.use_occlusions)
     filtered, inds = cache_ref.maybe_resample(cfg, history[-1], False)
-    sh = transient_shader(weights, cfg, rays, filtered, None)
+    occ, shadow_acc = shadow_occlusion(weights, cfg, rays, filtered, shadow_jitters) if t.use_occlusions else (None, None)
+    sh = transient_shader(weights, cfg, rays, filtered, occ)
     integ = transient_integrate(cfg, sh)
-    return {"sampler": history, "shader": sh, "integrator": integ, "render": integ}
+    return {"sampler": history, "shader": sh, "integrator": integ, "render": integ, "shadow_acc": shadow_acc}

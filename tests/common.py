@@ -70,16 +70,23 @@ def secondary_case(n, seed=5):
     return rays, rnd
 
 
-@functools.lru_cache(maxsize=2)
-def weights_transient_np(smooth=False):
+@functools.lru_cache(maxsize=3)
+def weights_transient_np(smooth=False, density_shift=0.0):
     kw = dict(level_decay=0.5, table_range=0.2) if smooth else {}
-    return nrc_amd.synthetic_weights(nrc_amd.cornell_transient_config(), **kw)
+    return nrc_amd.synthetic_weights(nrc_amd.cornell_transient_config(), density_shift=density_shift, **kw)
 
 
-def oracle_transient(n_rays, jitter_seed=None, seed=20200823, smooth=False, dtype=torch.float32):
+def shadow_jitters(n_shadow, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return [rng.uniform(size=(n_shadow, 1)).astype(np.float32) for _ in range(3)]
+
+
+def oracle_transient(n_rays, jitter_seed=None, seed=20200823, smooth=False, dtype=torch.float32, occlusions=False,
+                     shadow_jitter_seed=None, density_shift=0.0):
     """Time-resolved cornell cache on synthetic transient rays (oracle/transient_ref.py)."""
     from oracle import transient_ref
-    cfg = nrc_amd.cornell_transient_config()
+    cfg = nrc_amd.cornell_transient_config(use_occlusions=occlusions)
     rays = nrc_amd.synthetic_transient_rays(n_rays, seed=seed)
-    jit = None if jitter_seed is None else [torch.from_numpy(j) for j in jitters(n_rays, seed=jitter_seed)]
-    return transient_ref.transient_forward(to_torch(weights_transient_np(smooth), dtype), cfg, rays_torch(rays, dtype), jit)
+    jit = None if jitter_seed is None else [torch.from_numpy(j).to(dtype) for j in jitters(n_rays, seed=jitter_seed)]
+    sj = None if shadow_jitter_seed is None else [torch.from_numpy(j).to(dtype) for j in shadow_jitters(n_rays * 32, shadow_jitter_seed)]
+    return transient_ref.transient_forward(to_torch(weights_transient_np(smooth, density_shift), dtype), cfg, rays_torch(rays, dtype), jit, sj)

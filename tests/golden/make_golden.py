@@ -74,13 +74,15 @@ def operator_cases():
     print("operators.npz", list(d.keys()))
 
 
-def transient_case(n_rays, jitter_seed, name):
+def transient_case(n_rays, jitter_seed, name, occlusions=False, shadow_jitter_seed=None):
     """Time-resolved cornell cache (oracle/transient_ref.py) in float64; only the render dict is stored."""
-    out = common.oracle_transient(n_rays, jitter_seed=jitter_seed, dtype=F64)
+    out = common.oracle_transient(n_rays, jitter_seed=jitter_seed, dtype=F64, occlusions=occlusions,
+                                  shadow_jitter_seed=shadow_jitter_seed)
     d = {"render_" + k: v.numpy().astype(np.float32) for k, v in out["render"].items()
          if k not in ("transient_direct", "transient_indirect", "transient_direct_no_filter", "transient_indirect_no_filter",
                       "weights", "dists")}
-    d["meta"] = np.array([n_rays, -1 if jitter_seed is None else jitter_seed], dtype=np.float64)
+    d["meta"] = np.array([n_rays, -1 if jitter_seed is None else jitter_seed, 1 if occlusions else 0,
+                          -1 if shadow_jitter_seed is None else shadow_jitter_seed], dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, name), **d)
     print(name, sorted(d.keys())[:6], "...")
 
@@ -89,9 +91,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "transient":       # only the transient fixtures
         transient_case(16, None, "transient_16_det.npz")
         transient_case(16, 5, "transient_16_jit.npz")
+        transient_case(8, 5, "transient_8_occ.npz", occlusions=True, shadow_jitter_seed=13)
         sys.exit(0)
     transient_case(16, None, "transient_16_det.npz")
     transient_case(16, 5, "transient_16_jit.npz")
+    transient_case(8, 5, "transient_8_occ.npz", occlusions=True, shadow_jitter_seed=13)
     cache_case(256, None, 0.0, "hotdog_cache_256_det.npz")
     cache_case(256, 7, 0.0, "hotdog_cache_256_jit.npz")
     cache_case(64, 11, 4.0, "hotdog_cache_64_shell.npz")

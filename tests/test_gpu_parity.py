@@ -598,6 +598,23 @@ def test_transient_properties_full_batch_1024(rc_transient):
     assert np.array_equal(again["rgb"], rgb)
 
 
+def test_transient_dense_field_samples_share_bins():
+    """+6 on the density bias: the weight sits on a few adjacent samples whose time shifts coincide, so both
+    half-waves of k_transient_bins add into the same histogram entries."""
+    from nrc_amd import rc_ext
+    n = 24
+    h = rc_ext.RadianceCache(nrc_amd.cornell_transient_config(), 0)
+    h.load_weights(common.weights_transient_np(False, 6.0))
+    rays = nrc_amd.synthetic_transient_rays(n)
+    out = {k: v.cpu().numpy() for k, v in h.render_transient(rays.hot_fields(), {"jitter": common.jitters(n, seed=5)}).items()}
+    r = {k: v.numpy() for k, v in common.oracle_transient(n, jitter_seed=5, density_shift=6.0)["render"].items()}
+    assert r["acc"].min() > 0.99
+    for k in ("rgb", "transient_direct_viz", "transient_indirect_viz"):
+        assert np.abs(out[k] - r[k]).max() <= 1e-4 * max(1.0, np.abs(r[k]).max()), k
+    for k in ("indirect_rgb", "direct_rgb", "integrated_rgb"):
+        assert np.abs(out[k] - r[k]).max() <= 1e-4 * max(1.0, np.abs(r[k]).max()), k
+
+
 def test_transient_direct_spill_into_next_ray(rc_transient):
     """The direct scatter indexes the flattened [rays * bins] histogram (render.py:447-475): path lengths beyond
     700 bins of ray r show up at the start of ray r + 1 -- and nowhere for the last ray of the batch."""
@@ -638,3 +655,37 @@ def test_transient_model_apply_and_errors():
         h.render_transient(rays.hot_fields(), None)
     with pytest.raises(rc_ext.RcError):        # hotdog weights do not fit the transient inventory
         rc_ext.RadianceCache(nrc_amd.cornell_transient_config(), 0).load_weights(common.weights_np())
+
+
+def test_transient_occlusions_shadow_rays_vs_oracle():
+    """use_occlusions (vis_only): one weights-only shadow ray per shaded sample through the secondary-ray sampler
+    (analytic normals for the near offset, power-ladder distances, far = distance to the light - light_near).  Dense
+    field (+6 on the density bias) so that a good part of the shadow rays saturates."""
+    from nrc_amd import rc_ext
+    n = 24
+    cfg = nrc_amd.cornell_transient_config(use_occlusions=True)
+    h = rc_ext.RadianceCache(cfg, 0)
+    h.load_weights(common.weights_transient_np(False, 6.0))
+    rays = nrc_amd.synthetic_transient_rays(n)
+    rnd = {"jitter": common.jitters(n, seed=5), "shadow_jitter": common.shadow_jitters(n * 32, 13)}
+    out = {k: v.cpu().numpy() for k, v in h.render_transient(rays.hot_fields(), rnd).items()}
+    ref = common.oracle_transient(n, jitter_seed=5, occlusions=True, shadow_jitter_seed=13, density_shift=6.0)
+    acc_ref = ref["shadow_acc"].numpy().reshape(-1)
+    acc = h.workspace("sh_acc")[: n * 32]
+    # shadow rays start ON the surface of a white-noise field: same amplification of position ulps as for the
+    # primary rays, plus the discontinuous analytic normals that set their near plane (DESIGN.md section 6)
+    d = np.abs(acc - acc_ref)
+    assert np.median(d) <= 1e-5 and d.mean() <= 2e-3
+    occ_ref = ref["shader"]["occ"].numpy()[..., 0].reshape(-1)
+    lit = ref["shader"]["n_dot_l_rgb"].numpy()[..., 0].reshape(-1) > 0
+    assert 0.02 < (occ_ref[lit] > 0).mean() < 0.98
+    r = {k: v.numpy() for k, v in ref["render"].items()}
+    # rays whose thresholded occlusion pattern agrees (a shadow acc next to 0.9 may flip): tight; all rays: loose
+    same = np.all(((acc > 0.9) == (acc_ref > 0.9)).reshape(n, 32), axis=1)
+    assert same.mean() >= 0.9
+    same[1:] &= same[:-1].copy()          # the direct scatter of ray r - 1 spills into ray r (render.py:447-475)
+    for k in ("rgb", "transient_direct_viz", "transient_indirect_viz"):
+        assert np.abs(out[k][same] - r[k][same]).max() <= 5e-5, k
+    for k in ("occ", "direct_rgb", "integrated_rgb", "diffuse_rgb", "specular_rgb"):
+        assert np.abs(out[k][same] - r[k][same]).max() <= 2e-4 * max(1.0, np.abs(r[k]).max()), k
+    assert np.abs(out["transient_indirect_viz"] - r["transient_indirect_viz"]).max() <= 5e-5     # not touched by the shadows

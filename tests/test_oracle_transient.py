@@ -107,11 +107,26 @@ def test_transient_render_is_self_consistent():
     assert np.abs(sh["indirect_diffuse_rgb"].numpy() - sh["transient_indirect_diffuse"].numpy().sum(-2)).max() <= 1e-5
 
 
-@pytest.mark.parametrize("name", ["transient_16_det.npz", "transient_16_jit.npz"])
+def test_shadow_occlusion_thresholds_and_darkens():
+    """use_occlusions: occ is 0 or > occ_threshold, never in between; it can only remove direct light."""
+    a = common.oracle_transient(8, jitter_seed=5, density_shift=6.0)
+    b = common.oracle_transient(8, jitter_seed=5, occlusions=True, shadow_jitter_seed=13, density_shift=6.0)
+    occ = b["shader"]["occ"].numpy()
+    lit = b["shader"]["n_dot_l_rgb"].numpy() > 0
+    vals = occ[lit]
+    assert np.all((vals == 0) | (vals > 0.9)) and np.all(occ[~lit] == 1)
+    assert 0.02 < (vals > 0).mean() < 0.98                 # dense field (+6 on the density bias): some shadow rays saturate
+    assert np.all(b["render"]["direct_rgb"].numpy() <= a["render"]["direct_rgb"].numpy() * (1 + 1e-6) + 1e-7)
+    # the indirect part does not see the shadow rays
+    assert np.abs(a["render"]["transient_indirect_viz"].numpy() - b["render"]["transient_indirect_viz"].numpy()).max() <= 1e-7
+
+
+@pytest.mark.parametrize("name", ["transient_16_det.npz", "transient_16_jit.npz", "transient_8_occ.npz"])
 def test_transient_oracle_vs_golden(name):
     g = dict(np.load(os.path.join(GOLD, name)))
-    n, js = int(g["meta"][0]), int(g["meta"][1])
-    r = common.oracle_transient(n, jitter_seed=None if js < 0 else js)["render"]
+    n, js, occ, sjs = (int(v) for v in g["meta"])
+    r = common.oracle_transient(n, jitter_seed=None if js < 0 else js, occlusions=bool(occ),
+                                shadow_jitter_seed=None if sjs < 0 else sjs)["render"]
     for k in ("rgb", "integrated_rgb", "acc", "diffuse_rgb", "specular_rgb", "distance_median"):
         want = g["render_" + k]
         got = r[k].numpy()
