@@ -102,6 +102,47 @@ def transient_line(local_rank, dev, n_rays=1024, steps=20, warmup=3):
             "note": "output allocation (3 x [1024,700,3] fp32 zero-fills) is inside the step"}
 
 
+def material_line(local_rank, dev, n_rays=1024, steps=5, warmup=2):
+    """Secondary measurement (not part of `value`): rc_render_material on 1024 synthetic hotdog rays =
+    material / light heads, 32 importance-sampled secondary rays per primary ray traced through the cache
+    (32 768 secondary rays per step), Monte-Carlo BRDF integration (BASELINE configs[2])."""
+    import numpy as np
+    import torch
+
+    import nrc_amd
+    from nrc_amd import rc_ext
+
+    cfg = nrc_amd.hotdog_config()
+    rc = rc_ext.RadianceCache(cfg, local_rank)
+    rc.load_weights(nrc_amd.synthetic_weights(cfg, passes=("cache", "material")))
+    rays = nrc_amd.synthetic_rays(n_rays)
+    f = {k: torch.from_numpy(np.asarray(v)).to(dev).contiguous() for k, v in rays.hot_fields().items()}
+    rng = np.random.Generator(np.random.PCG64(0))
+    K, S = cfg.num_secondary_samples, cfg.sampling_strategy[-1][2]
+    Kd = int(round(K * cfg.diffuse_sample_fraction))
+    Ks, kc = K - Kd, int(round(0.5 * int(round(K * cfg.diffuse_sample_fraction))))
+    u = lambda *shape: torch.from_numpy(rng.uniform(size=shape).astype(np.float32)).to(dev)
+    g = lambda *shape: torch.from_numpy(rng.gumbel(size=shape).astype(np.float32)).to(dev)
+    rnd = dict(jitter=[u(n_rays) for _ in range(3)], gumbel=g(n_rays, S),
+               vmf_noise=torch.from_numpy(rng.normal(size=(n_rays, cfg.num_vmf, 3)).astype(np.float32)).to(dev),
+               spec_u1=u(n_rays, Ks), spec_u2=u(n_rays, Ks), cos_u1=u(n_rays, kc), cos_u2=u(n_rays, kc),
+               vmf_lobe=torch.from_numpy(rng.integers(0, cfg.num_vmf, size=(n_rays,)).astype(np.int32)).to(dev),
+               vmf_v=torch.from_numpy(rng.normal(size=(n_rays, Kd - kc, 2)).astype(np.float32)).to(dev), vmf_tmp=u(n_rays, Kd - kc),
+               spec_jitter=[u(n_rays * Ks) for _ in range(3)], spec_gumbel=g(n_rays * Ks, S),
+               diff_jitter=[u(n_rays * Kd) for _ in range(3)], diff_gumbel=g(n_rays * Kd, S))
+    for _ in range(warmup):
+        rc.render_material(f, rnd)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rc.render_material(f, rnd)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"workload": "hotdog material stage, 1024 primary rays x 32 secondary rays x (64,64,32) samples (configs[2])",
+            "primary_rays_per_s": n_rays / (ms * 1e-3), "secondary_rays_per_s": n_rays * K / (ms * 1e-3),
+            "ms_per_step": ms, "steps": steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +151,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-transient", action="store_true",
                     help="skip the secondary measurement of the time-resolved cache (configs[4])")
+    ap.add_argument("--no-material", action="store_true",
+                    help="skip the secondary measurement of the material stage (configs[2])")
     ap.add_argument("--graph-mode", type=int, default=2, help="0 eager, 1 lazy hipGraph, 2 hipGraph at once")
     ap.add_argument("--plan", choices=("fused", "staged"), default="fused",
                     help="fused: one launch per batch (rc_set_fused 1, default); staged: one launch per stage")
@@ -241,6 +284,8 @@ def main():
     }
     if not args.no_transient and world == 1:
         res["transient"] = transient_line(local_rank, dev)
+    if not args.no_material and world == 1:
+        res["material"] = material_line(local_rank, dev)
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline(cfg, weights, RAYS_PER_BATCH)
     else:
