@@ -419,7 +419,32 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sd[u][r] = 0.0f; ss[u][r] = 0.0f; }
 
-  auto tile_body = [&](const int T, float (&sdu)[16], float (&ssu)[16]) __attribute__((always_inline)) {
+  // Per-sample terms of this lane's 16 samples, kept in registers for all 66 tiles: weight, time shift, and the
+  // window of bins that survive zero_invalid_bins (render_utils.py:1699-1767).  Both travel-time tests are monotone
+  // in the bin index, so each is a bound: bins >= b_lo pass "(b + thr) * e < light_dist" (too close), bins <= b_hi
+  // pass "b * e + cam_dist > max_dists" (too far); the bounds are settled with the very comparisons of the reference.
+  float rw[16], rdm[16];
+  int rlo[16], rhi[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+    rw[r] = sp[P_W * 32 + i];
+    rdm[r] = sp[P_DIND * 32 + i];
+    const float ld = sp[P_LDIST * 32 + i], cdist = sp[P_CAMDIST * 32 + i];
+    auto close = [&](int b) { return (float)(b + a.bin_zero_threshold_light) * a.exposure < ld; };
+    auto far = [&](int b) { return ((float)b * a.exposure + cdist) > max_dists; };
+    int lo = (int)ceilf(ld / a.exposure) - a.bin_zero_threshold_light;
+    lo = min(max(lo, 0), kBins);
+    while (lo > 0 && !close(lo - 1)) --lo;
+    while (lo < kBins && close(lo)) ++lo;
+    int hi = (int)floorf((max_dists - cdist) / a.exposure);
+    hi = min(max(hi, -1), kBins - 1);
+    while (hi < kBins - 1 && !far(hi + 1)) ++hi;
+    while (hi >= 0 && far(hi)) --hi;
+    if (sp[P_KILL * 32 + i] != 0.0f) { lo = kBins; hi = -1; }
+    rlo[r] = lo; rhi[r] = hi;
+  }
+  auto tile_body = [&](const int T, const int u, float (&sdu)[16], float (&ssu)[16]) __attribute__((always_inline)) {
     {
       f32x16 as = zero16(), ai = zero16();
       tile_xw<65>(ws, T * kFragsPerTile, kBinFrags, xs, as);
@@ -427,29 +452,27 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
       const int f = T * 32 + fl;                   // histogram entry of this lane
       const bool fok = f < kHist;
       const int b = f / 3, c = f - 3 * b;
-      const float hist_light = (float)(b + a.bin_zero_threshold_light) * a.exposure;   // render_utils.py:1713
-      const float hist_cam = (float)b * a.exposure;                                    // :1729
       float cd = 0.0f, cs = 0.0f;                  // unshifted composites over this half-wave's 16 samples
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+        // a sample whose window misses every bin of this tile contributes exact zeros: skip it for the whole wave
+        const bool live = fok && b >= rlo[r] && b <= rhi[r];
+        if (__ballot(live) == 0ull) continue;
         const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float w = sp[P_W * 32 + i];
+        const float w = rw[r];
         // nerf.py:1795-1797 and :1712-1719: softplus(. + irradiance_bias) * indirect_scale;
         // surface_light_field.py:1037-1058 and nerf.py:1721-1723: tint * ibrdf * clip(softplus(. + rgb_bias), 0) * scale
         float diff = softplus_hw(ai[r] + a.irradiance_bias) * a.indirect_scale;
         const float ref = fmaxf(softplus_hw(1.0f * as[r] + a.slf_rgb_bias), 0.0f);
-        const float tib = c == 0 ? sp[P_TIB0 * 32 + i] : (c == 1 ? sp[P_TIB1 * 32 + i] : sp[P_TIB2 * 32 + i]);
+        const float tib = sp[(P_TIB0 + c) * 32 + i];
         float spec = (tib * ref) * a.indirect_scale;
-        // zero_invalid_bins (render_utils.py:1699-1767)
-        const bool kill = (hist_light < sp[P_LDIST * 32 + i]) | ((hist_cam + sp[P_CAMDIST * 32 + i]) > max_dists) |
-                          (sp[P_KILL * 32 + i] != 0.0f) | !fok;
-        diff = kill ? 0.0f : fminf(fmaxf(diff, 0.0f), a.rgb_max);             // nerf.py:1757-1758
-        spec = kill ? 0.0f : fminf(fmaxf(spec, 0.0f), a.rgb_max);
+        diff = live ? fminf(fmaxf(diff, 0.0f), a.rgb_max) : 0.0f;             // nerf.py:1757-1758
+        spec = live ? fminf(fmaxf(spec, 0.0f), a.rgb_max) : 0.0f;
         sdu[r] += diff; ssu[r] += spec;
         cd += w * diff; cs += w * spec;
         // shift_map_coordinates (render.py:480-496): out[y] = in(y - d), linear, zero outside.  Entry b of this
         // sample reaches y = b + floor(d) and y + 1; the weights are those the target bin computes.
-        const float dmove = sp[P_DIND * 32 + i];
+        const float dmove = rdm[r];
         const int y0 = b + (int)floorf(dmove);
         const float val = w * (diff + spec);
 #pragma unroll
@@ -459,10 +482,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
           const float i0 = floorf(t);
           const float fw = t - i0;
           const float wt = ((int)i0 == b ? 1.0f - fw : 0.0f) + ((int)i0 + 1 == b ? fw : 0.0f);
-          const bool ok = fok && y >= 0 && y < kBins;
+          const bool ok = live && y >= 0 && y < kBins;
           // the two half-waves work on different samples and may meet in one entry: one after the other
-          // (within a half-wave the 32 lanes hold 32 different entries of ONE sample: plain read-add-write; the
-          // wave barrier keeps the compiler from merging the two phases into one colliding instruction)
+          // (within a half-wave the 32 lanes hold 32 different entries of ONE sample: plain read-add-write, which
+          // measured faster than ds_add_f32; the wave barrier keeps the compiler from merging the two phases into
+          // one colliding instruction)
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
             if (ok && h == hh) hist_i[y * 3 + c] = hist_i[y * 3 + c] + val * wt;
@@ -479,9 +503,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
     }
   };
   for (int T3 = 0; T3 < kTilesB / 3; ++T3) {
-    tile_body(T3 * 3 + 0, sd[0], ss[0]);
-    tile_body(T3 * 3 + 1, sd[1], ss[1]);
-    tile_body(T3 * 3 + 2, sd[2], ss[2]);
+    tile_body(T3 * 3 + 0, 0, sd[0], ss[0]);
+    tile_body(T3 * 3 + 1, 1, sd[1], ss[1]);
+    tile_body(T3 * 3 + 2, 2, sd[2], ss[2]);
   }
   // ---- per-sample sums over the bins: pick the channel of each tile phase, add up the 32 entry lanes
   {
