@@ -322,6 +322,29 @@ typedef struct rc_transient_outputs { float* ptr[RC_TOUT_COUNT]; } rc_transient_
 int rc_render_transient(rc_handle* h, const rc_rays* rays, const float* cam_origins, int64_t n, const rc_randoms* rnd,
                         const rc_randoms* shadow_rnd, const rc_transient_outputs* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * On-device ray generation: camera_utils.pixels_to_rays + cast_ray_batch
+ * (internal/camera_utils.py:896-1072, 1225-1329) for one pinhole camera (ProjectionType.PERSPECTIVE,
+ * no distortion / NDC / z_range / pixel jitter).  The outputs are the device arrays rc_rays points to.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct rc_camera {
+  float pixtocam[9];     /* inverse intrinsics, row-major [3,3] (camera_utils.get_pixtocam)              */
+  float camtoworld[12];  /* extrinsics, row-major [3,4]                                                  */
+  float light[3];        /* lights[cam_idx] (camera_utils.py:1288)                                       */
+  float near, far;       /* Pixels.near / Pixels.far                                                     */
+} rc_camera;
+typedef struct rc_cast_outputs {
+  float* origins; float* directions; float* viewdirs;   /* [n,3] */
+  float* radii;                                         /* [n]   */
+  float* imageplane;                                    /* [n,2] */
+  float* look; float* up; float* lights;                /* [n,3] */
+  float* near; float* far;                              /* [n]   */
+} rc_cast_outputs;                                      /* NULL = not wanted */
+/* pix_x / pix_y: int32 device arrays [n] (Pixels.pix_x_int / pix_y_int), or both NULL for the rectangle
+ * [x0, x0 + width) x [y0, y0 + height) in row-major order (n = width * height). */
+int rc_cast_rays(rc_handle* h, const rc_camera* cam, const int32_t* pix_x, const int32_t* pix_y, int64_t n,
+                 int32_t x0, int32_t y0, int32_t width, int32_t height, const rc_cast_outputs* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,60 @@
+"""Host mirror of the reference's ray generation for pinhole cameras, running on the GPU.
+
+    cast_ray_batch(rc, camera, pixels) -> Rays   camera_utils.cast_ray_batch   internal/camera_utils.py:1225-1329
+    get_pixtocam(focal, width, height)           camera_utils.get_pixtocam     internal/camera_utils.py:760-763
+    render_camera(model, camera, height, width)  trainer.render_primary_rays   engine/trainer.py:812-846 (pose in, image out)
+
+Only what the BASELINE scenes use: ProjectionType.PERSPECTIVE, no distortion / NDC / z_range / pixel jitter.
+The returned Rays hold torch cuda tensors (nothing crosses PCIe but the 3x3 + 3x4 matrices).
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Optional
+
+import numpy as np
+
+from .rays import Rays
+
+
+def get_pixtocam(focal: float, width: int, height: int) -> np.ndarray:
+    camtopix = np.array([[focal, 0, width * 0.5], [0, focal, height * 0.5], [0, 0, 1.0]])
+    return np.linalg.inv(camtopix)
+
+
+@dataclasses.dataclass
+class Camera:
+    """One entry of the reference's `cameras` tuple (pixtocams[i], camtoworlds[i]) + its light and depth range."""
+
+    pixtocam: np.ndarray          # [3, 3]
+    camtoworld: np.ndarray        # [3, 4]
+    light: Optional[np.ndarray] = None   # [3]; default: the camera centre (datasets.py:1348)
+    near: float = 2.0
+    far: float = 6.0
+
+
+def cast_ray_batch(rc, camera: Camera, pix_x_int=None, pix_y_int=None, rect=None) -> Rays:
+    """Rays for an explicit pixel batch (int arrays of one shape) or for rect = (x0, y0, width, height)."""
+    return rc.cast_rays(camera, pix_x_int, pix_y_int, rect)
+
+
+def render_camera(model, camera: Camera, height: int, width: int, passes=("cache",), rows_per_chunk: Optional[int] = None,
+                  keys=("rgb", "acc", "distance_median")):
+    """Image of one camera without a host-side ray batch: rows of pixels are cast on the device and rendered
+    chunk by chunk; returns {key: numpy [H, W, ...]}."""
+    import torch
+
+    chunk = model.config.render_chunk_size
+    rows = rows_per_chunk or max(1, chunk // width)
+    out = {}
+    for y0 in range(0, height, rows):
+        hgt = min(rows, height - y0)
+        rays = cast_ray_batch(model.rc, camera, rect=(0, y0, width, hgt))
+        r = model.apply(None, None, rays, passes=passes)["render"]
+        for k in keys:
+            v = r[k]
+            if k not in out:
+                out[k] = torch.empty((height, width) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+            out[k][y0:y0 + hgt] = v.reshape((hgt, width) + tuple(v.shape[1:]))
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}

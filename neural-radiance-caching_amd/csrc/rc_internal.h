@@ -279,3 +279,18 @@ int rc_transient_shader_frags();
 int rc_transient_bins_frags();
 void rc_launch_transient_shader(const RcTransShaderArgs& a, hipStream_t stream);
 void rc_launch_transient_bins(const RcTransBinsArgs& a, hipStream_t stream);
+
+
+// ---------------------------------------------------------------------------------------------
+// On-device ray generation (rc_camera.hip)
+// ---------------------------------------------------------------------------------------------
+struct RcCastArgs {
+  int64_t n;
+  const int32_t* pix_x; const int32_t* pix_y;      // explicit pixel batch, or NULL: the rectangle below, row-major
+  int32_t x0, y0, width;
+  float pixtocam[9]; float rot[9]; float trans[3]; float light[3];
+  float near_v, far_v;
+  float* origins; float* directions; float* viewdirs; float* radii; float* imageplane; float* look; float* up;
+  float* lights; float* near; float* far;
+};
+void rc_launch_cast_rays(const RcCastArgs& a, hipStream_t stream);

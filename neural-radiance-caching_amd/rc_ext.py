@@ -124,10 +124,23 @@ class rc_transient_outputs(C.Structure):
     _fields_ = [("ptr", C.c_void_p * RC_TOUT_COUNT)]
 
 
+class rc_camera(C.Structure):
+    _fields_ = [("pixtocam", C.c_float * 9), ("camtoworld", C.c_float * 12), ("light", C.c_float * 3),
+                ("near", C.c_float), ("far", C.c_float)]
+
+
+CAST_OUTPUTS = (("origins", 3), ("directions", 3), ("viewdirs", 3), ("radii", 1), ("imageplane", 2), ("look", 3), ("up", 3),
+                ("lights", 3), ("near", 1), ("far", 1))
+
+
+class rc_cast_outputs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k, _ in CAST_OUTPUTS]
+
+
 EXPORTS = (
     "rc_create", "rc_destroy", "rc_last_error", "rc_abi_version", "rc_load_weights", "rc_render_rays",
     "rc_hashgrid_lookup", "rc_sample_intervals", "rc_workspace_ptr", "rc_set_profiling", "rc_stage_count",
-    "rc_stage_name", "rc_stage_times_ms", "rc_set_graph_mode", "rc_set_fused", "rc_render_material", "rc_set_transient", "rc_render_transient",
+    "rc_stage_name", "rc_stage_times_ms", "rc_set_graph_mode", "rc_set_fused", "rc_render_material", "rc_set_transient", "rc_render_transient", "rc_cast_rays",
 )
 
 _LIB = None
@@ -182,6 +195,9 @@ def load_library():
     lib.rc_render_transient.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]
     lib.rc_render_transient.restype = C.c_int
+    lib.rc_cast_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                 C.c_int32, C.c_void_p, C.c_void_p]
+    lib.rc_cast_rays.restype = C.c_int
     lib.rc_stage_count.restype = C.c_int
     lib.rc_stage_name.argtypes = [C.c_int32]
     lib.rc_stage_name.restype = C.c_char_p
@@ -379,6 +395,49 @@ class RadianceCache:
             if t.shape[0] != n:
                 raise ValueError(f"ray field {k} has {t.shape[0]} rows, expected {n}")
         return r, held, n
+
+    def cast_rays(self, camera, pix_x_int=None, pix_y_int=None, rect=None):
+        """rc_cast_rays: pinhole rays of `camera` (pixtocam [3,3], camtoworld [3,4], light, near, far) for an explicit
+        pixel batch (two int arrays of one shape) or for rect = (x0, y0, width, height), as a Rays of cuda tensors
+        with the batch shape of the pixels ([h, w, .] for a rectangle)."""
+        from .rays import Rays
+        torch = self._torch
+        cam = rc_camera()
+        p2c = np.asarray(camera.pixtocam, np.float32).reshape(9)
+        c2w = np.asarray(camera.camtoworld, np.float32).reshape(12)
+        light = c2w.reshape(3, 4)[:, 3] if camera.light is None else np.asarray(camera.light, np.float32).reshape(3)
+        for i in range(9):
+            cam.pixtocam[i] = float(p2c[i])
+        for i in range(12):
+            cam.camtoworld[i] = float(c2w[i])
+        for i in range(3):
+            cam.light[i] = float(light[i])
+        cam.near, cam.far = float(camera.near), float(camera.far)
+        dev = f"cuda:{self.device}"
+        if rect is not None:
+            x0, y0, w, hgt = (int(v) for v in rect)
+            shape, n, px, py = (hgt, w), w * hgt, None, None
+        else:
+            px = self._dev(np.ascontiguousarray(pix_x_int), torch.int32)
+            py = self._dev(np.ascontiguousarray(pix_y_int), torch.int32)
+            if px.shape != py.shape:
+                raise ValueError("pix_x_int and pix_y_int must have the same shape")
+            shape, n, x0, y0, w, hgt = tuple(px.shape), px.numel(), 0, 0, 0, 0
+        out = rc_cast_outputs()
+        t = {}
+        for k, width in CAST_OUTPUTS:
+            t[k] = torch.empty(shape + (width,), dtype=torch.float32, device=dev)
+            setattr(out, k, t[k].data_ptr())
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.rc_cast_rays(self._h, C.byref(cam), px.data_ptr() if px is not None else None,
+                                          py.data_ptr() if py is not None else None, n, x0, y0, w, hgt, C.byref(out), stream))
+        self._keep = [px, py]
+        ones = torch.ones(shape + (1,), dtype=torch.float32, device=dev)
+        zi = torch.zeros(shape + (1,), dtype=torch.int32, device=dev)
+        return Rays(origins=t["origins"], lights=t["lights"], directions=t["directions"], viewdirs=t["viewdirs"],
+                    radii=t["radii"], imageplane=t["imageplane"], look=t["look"], up=t["up"], cam_origins=t["origins"],
+                    vcam_look=t["look"], vcam_up=t["up"], vcam_origins=t["origins"], lossmult=ones, near=t["near"],
+                    far=t["far"], cam_idx=zi, light_idx=zi)
 
     def render_transient(self, rays: Dict[str, object], randoms: Optional[Dict[str, object]] = None,
                          outputs: Optional[Iterable[str]] = None):

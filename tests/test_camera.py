@@ -1,0 +1,95 @@
+"""On-device ray generation: oracle KATs on the CPU, parity of rc_cast_rays on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+import nrc_amd
+from oracle import camera_ref
+
+
+def _lookat(origin):
+    o = np.asarray(origin, np.float64)
+    look = -o / np.linalg.norm(o)
+    right = np.cross(look, [0.0, 0.0, 1.0]); right /= np.linalg.norm(right)
+    up = np.cross(right, look)
+    # OpenGL camera: columns = right, up, -look
+    return np.concatenate([np.stack([right, up, -look], axis=1), o[:, None]], axis=1)
+
+
+def test_pixels_to_rays_known_answers():
+    H, W, f = 8, 10, 12.5
+    p2c = camera_ref.get_pixtocam(f, W, H)
+    assert np.allclose(p2c @ np.array([W / 2, H / 2, 1.0]), [0, 0, 1])
+    c2w = _lookat([0.0, -3.0, 4.0])
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H), indexing="xy")
+    r = camera_ref.pixels_to_rays(xs, ys, p2c, c2w, np.float64)
+    # a pixel whose centre is the principal point does not exist for even sizes; the four central ones straddle `look`
+    centre = r["directions"][H // 2 - 1:H // 2 + 1, W // 2 - 1:W // 2 + 1].mean((0, 1))
+    assert np.allclose(centre / np.linalg.norm(centre), -np.asarray([0.0, -3.0, 4.0]) / 5.0, atol=1e-12)
+    assert np.allclose(np.linalg.norm(r["viewdirs"], axis=-1), 1.0)
+    assert np.allclose(r["origins"], [0.0, -3.0, 4.0])
+    assert np.allclose(r["look"][0, 0], c2w[:, 2] * -1) and np.allclose(r["up"][0, 0], c2w[:, 1])
+    # image plane: x right, y up (OpenGL), one pixel = 1 / f
+    assert np.allclose(r["imageplane"][0, 0], [(0.5 - W / 2) / f, -(0.5 - H / 2) / f])
+    assert np.allclose(np.diff(r["imageplane"][..., 0], axis=1), 1 / f) and np.allclose(np.diff(r["imageplane"][..., 1], axis=0), -1 / f)
+    # radii: neighbours are exactly one pixel (1 / f) away on the image plane, rotation keeps lengths
+    assert np.allclose(r["radii"], (1 / f) * 2 / np.sqrt(12))
+    # un-normalised pinhole directions: z (camera) component is -1 before the rotation
+    cam_dirs = r["directions"] @ c2w[:, :3]
+    assert np.allclose(cam_dirs[..., 2], -1.0)
+
+
+def test_cast_ray_batch_fields():
+    p2c = camera_ref.get_pixtocam(50.0, 6, 4)
+    c2w = _lookat([1.0, 2.0, 2.0])
+    r = camera_ref.cast_ray_batch(p2c, c2w, [0.5, 0.5, 3.0], np.array([0, 5]), np.array([3, 0]), 0.7, 4.0)
+    assert r["origins"].shape == (2, 3) and r["near"].shape == (2, 1) and r["radii"].shape == (2, 1)
+    assert np.allclose(r["lights"], [0.5, 0.5, 3.0]) and np.all(r["near"] == np.float32(0.7)) and r["cam_origins"] is r["origins"]
+    assert r["directions"].dtype == np.float32
+
+
+@pytest.mark.gpu
+def test_cast_rays_on_device_matches_oracle():
+    from nrc_amd import rc_ext
+    rc = rc_ext.RadianceCache(nrc_amd.hotdog_config(), 0)
+    H, W, f = 37, 53, 61.0
+    cam = nrc_amd.Camera(nrc_amd.get_pixtocam(f, W, H), _lookat([2.0, -3.0, 1.5]), light=[2.1, -3.0, 1.6], near=2.0, far=6.0)
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H), indexing="xy")
+    ref = camera_ref.cast_ray_batch(cam.pixtocam, cam.camtoworld, cam.light, xs, ys, 2.0, 6.0)
+    rect = rc.cast_rays(cam, rect=(0, 0, W, H))
+    torch.cuda.synchronize()
+    for k in ("origins", "directions", "viewdirs", "radii", "imageplane", "look", "up", "lights", "near", "far"):
+        got = getattr(rect, k).cpu().numpy()
+        assert got.shape == ref[k].shape, k
+        assert np.abs(got - ref[k]).max() <= 2e-6 * max(1.0, np.abs(ref[k]).max()), k
+    # explicit, unordered pixel batch and a sub-rectangle
+    rng = np.random.default_rng(0)
+    px, py = rng.integers(0, W, size=(5, 7)), rng.integers(0, H, size=(5, 7))
+    batch = rc.cast_rays(cam, px, py)
+    sub = rc.cast_rays(cam, rect=(11, 5, 20, 9))
+    torch.cuda.synchronize()
+    assert torch.equal(batch.directions, rect.directions[torch.from_numpy(py), torch.from_numpy(px)])
+    assert torch.equal(sub.directions, rect.directions[5:14, 11:31]) and torch.equal(sub.radii, rect.radii[5:14, 11:31])
+
+
+@pytest.mark.gpu
+def test_render_camera_equals_render_of_host_rays():
+    """Pose in, image out: rays cast on the device give the image of the same rays uploaded from the host."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import common
+    from nrc_amd import model as M
+    H, W, f = 20, 24, 30.0
+    cfg = nrc_amd.hotdog_config(render_chunk_size=128)
+    m = M.Model(cfg, 0)
+    m.load_variables(common.weights_np())
+    cam = nrc_amd.Camera(nrc_amd.get_pixtocam(f, W, H), _lookat([0.0, -3.5, 2.0]), near=2.0, far=6.0)
+    img = nrc_amd.render_camera(m, cam, H, W)
+    assert img["rgb"].shape == (H, W, 3) and img["acc"].shape == (H, W)
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H), indexing="xy")
+    ref = camera_ref.cast_ray_batch(cam.pixtocam, cam.camtoworld, cam.camtoworld[:, 3], xs, ys, 2.0, 6.0)
+    fields = {k: np.ascontiguousarray(ref[k].reshape(H * W, -1)) for k in ("origins", "directions", "viewdirs", "near", "far", "lights")}
+    out = m.rc.render_rays(fields, None, outputs=["rgb", "acc"])
+    torch.cuda.synchronize()
+    assert np.abs(img["rgb"].reshape(-1, 3) - out["rgb"].cpu().numpy()).max() <= 1e-4      # ray fields agree to 2e-6
+    assert np.abs(img["acc"].reshape(-1) - out["acc"].cpu().numpy()).max() <= 1e-4
