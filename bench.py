@@ -44,30 +44,57 @@ PEAK_HBM_GBS = 8000.0
 PMC_KIB = {"fused": 150880.0 + 248.0, "shader": 8933.5 + 1920.0}
 
 
+def host_cpu_share(cap=16):
+    """CPUs this process may really use: scheduler affinity, the cgroup CPU quota, capped at the one-GPU share of
+    the box (oversubscribing torch's intra-op pool on a quota-limited container stalls for minutes)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, cap))
+
+
 def cpu_baseline(cfg, weights_np, n_rays, budget_s=20.0):
-    """Oracle (torch fp32, all host cores) on the same 1024-ray batch; bounded to ~budget_s."""
+    """Oracle (torch fp32 on the host cores this process may use) on the same 1024-ray batch.  Bounded: every pass
+    is timed (the first one too), passes stop once `budget_s` is spent; progress goes to stderr."""
     import numpy as np
     import torch
 
     import nrc_amd
     from oracle import cache_ref
 
-    cores = os.cpu_count() or 1
+    cores = host_cpu_share()
     torch.set_num_threads(cores)
     wt = {k: torch.from_numpy(v) for k, v in weights_np.items()}
     rays = nrc_amd.synthetic_rays(n_rays)
     rt = {k: torch.from_numpy(np.asarray(v)) for k, v in rays.hot_fields().items()}
     run = lambda: cache_ref.cache_forward(wt, cfg, rt, None, want_grad_normals=True, exec_dead_envmap=True)
-    run()  # warm-up
     times = []
-    t_end = time.time() + budget_s
-    while len(times) < 10 and (time.time() < t_end or len(times) < 2):
+    t_start = time.time()
+    while len(times) < 8 and (time.time() - t_start < budget_s or len(times) < 1):
         t0 = time.time()
         run()
         times.append(time.time() - t0)
-    med = sorted(times)[len(times) // 2]
+        print(f"[bench] cpu_baseline pass {len(times)}: {times[-1]:.2f} s on {cores} threads", file=sys.stderr, flush=True)
+    timed = times[1:] if len(times) > 1 else times          # the first pass warms the allocator / thread pool up
+    med = sorted(timed)[len(timed) // 2]
     return {"value": n_rays / med, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} timed passes of one {n_rays}-ray batch (64,64,32 samples), torch fp32 oracle "
+            "sample": f"{len(timed)} timed passes of one {n_rays}-ray batch (64,64,32 samples), torch fp32 oracle "
                       f"incl. the reference's dead cache-EnvMap MLP and autograd normals; median {med*1e3:.0f} ms"}
 
 
@@ -283,8 +310,10 @@ def main():
         "stage_ms_separate_pass_staged_plan": stage,
     }
     if not args.no_transient and world == 1:
+        print("[bench] main measurement done; transient line ...", file=sys.stderr, flush=True)
         res["transient"] = transient_line(local_rank, dev)
     if not args.no_material and world == 1:
+        print("[bench] material line ...", file=sys.stderr, flush=True)
         res["material"] = material_line(local_rank, dev)
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline(cfg, weights, RAYS_PER_BATCH)
