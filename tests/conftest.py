@@ -29,3 +29,28 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def _cpu_share(cap=16):
+    """CPUs this process may really use (affinity + cgroup quota): torch's default of one thread per visible core
+    oversubscribes a quota-limited container (256 visible, 16 granted on the GPU boxes) and crawls."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
+def pytest_sessionstart(session):
+    try:
+        import torch
+        torch.set_num_threads(_cpu_share())
+    except Exception:
+        pass
