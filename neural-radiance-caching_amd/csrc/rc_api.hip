@@ -413,21 +413,46 @@ int repack(rc_handle* h) {
   {
     std::vector<float> stream;
     std::vector<Step> s;
+    // The shader bottleneck is linear and only feeds linear layers: fold it (fp64 products) into SLF layer_0, the
+    // input part of SLF layer_bottleneck and integrated_brdf_layers_0 (see rc_dev_mlp.h, kShActSteps).
+    const int FE = bott->in, BW = bott->out;                 // 96, 128
+    auto fold = [&](const HostLayer* L, int row0, int extra_rows) {
+      // rows [row0, row0 + BW) of L consume the bottleneck; the following `extra_rows` rows are kept as they are
+      HostLayer f;
+      f.in = FE + extra_rows; f.out = L->out;
+      f.kernel.assign((size_t)f.in * f.out, 0.0f); f.bias.assign(f.out, 0.0f);
+      f.have_kernel = f.have_bias = true;
+      for (int o = 0; o < L->out; ++o) {
+        for (int i = 0; i < FE; ++i) {
+          double a = 0.0;
+          for (int m = 0; m < BW; ++m) a += (double)bott->kernel[(size_t)i * BW + m] * (double)L->kernel[(size_t)(row0 + m) * L->out + o];
+          f.kernel[(size_t)i * f.out + o] = (float)a;
+        }
+        double b = 0.0;
+        for (int m = 0; m < BW; ++m) b += (double)bott->bias[m] * (double)L->kernel[(size_t)(row0 + m) * L->out + o];
+        f.bias[o] = (float)b;                                 // the layer's own bias is added where it is packed
+        for (int e = 0; e < extra_rows; ++e) f.kernel[(size_t)(FE + e) * f.out + o] = L->kernel[(size_t)(row0 + BW + e) * L->out + o];
+      }
+      return f;
+    };
+    HostLayer l0f = fold(l0, 0, 72), lbf = fold(lb, 128, 72), i0f = fold(i0, 0, 1);
+    for (int o = 0; o < l0->out; ++o) l0f.bias[o] = (float)((double)l0f.bias[o] + (double)l0->bias[o]);
+    for (int o = 0; o < lb->out; ++o) lbf.bias[o] = (float)((double)lbf.bias[o] + (double)lb->bias[o]);
+    for (int o = 0; o < i0->out; ++o) i0f.bias[o] = (float)((double)i0f.bias[o] + (double)i0->bias[o]);
     // heads: feature = [density feature (acc order) | appearance (natural)] + bias
     steps_acc(s, 2, 0); steps_natural(s, 32, 64); step_bias(s);
     std::vector<Col> regs = {Col{rough, 0}, Col{tint, 0}, Col{tint, 1}, Col{tint, 2}, Col{amb, 0},
                              Col{amb, 1},   Col{amb, 2},  Col{irr, 0},  Col{irr, 1},  Col{irr, 2}};
-    append(stream, pack(s, {tile_full(bott, 0), tile_full(bott, 1), tile_full(bott, 2), tile_full(bott, 3),
-                            tile_by_reg(regs)}));
-    // s0: SLF layer_0 + input part of layer_bottleneck over [bottleneck | IDE (real | imag) | bias]
-    s.clear(); steps_acc(s, 4, 0);
-    for (int i = 0; i < 36; ++i) s.push_back({{128 + i, 128 + 36 + i}});
+    append(stream, pack(s, {tile_by_reg(regs)}));
+    // s0: folded SLF layer_0 + folded input part of layer_bottleneck over [feature | IDE (real | imag) | bias]
+    s.clear(); steps_acc(s, 2, 0); steps_natural(s, 32, 64);
+    for (int i = 0; i < 36; ++i) s.push_back({{FE + i, FE + 36 + i}});
     step_bias(s);
-    append(stream, pack(s, {tile_full(l0, 0), tile_full(l0, 1), tile_full(l0, 2), tile_full(l0, 3),
-                            tile_full(lb, 0, 128), tile_full(lb, 1, 128), tile_full(lb, 2, 128), tile_full(lb, 3, 128)}));
-    // integrated BRDF
-    s.clear(); steps_acc(s, 4, 0); s.push_back({{128, -2}});         // (n.v | bias)
-    append(stream, pack(s, {tile_full(i0, 0), tile_full(i0, 1)}));
+    append(stream, pack(s, {tile_full(&l0f, 0), tile_full(&l0f, 1), tile_full(&l0f, 2), tile_full(&l0f, 3),
+                            tile_full(&lbf, 0), tile_full(&lbf, 1), tile_full(&lbf, 2), tile_full(&lbf, 3)}));
+    // integrated BRDF: folded first layer on [feature | (n.v | bias)]
+    s.clear(); steps_acc(s, 2, 0); steps_natural(s, 32, 64); s.push_back({{FE, -2}});
+    append(stream, pack(s, {tile_full(&i0f, 0), tile_full(&i0f, 1)}));
     s.clear(); steps_acc(s, 2, 0); step_bias(s);
     append(stream, pack(s, {tile_full(i1, 0), tile_full(i1, 1)}));
     append(stream, pack(s, {tile_by_reg({Col{io, 0}})}));

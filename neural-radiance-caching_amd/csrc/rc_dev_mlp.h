@@ -210,14 +210,19 @@ __host__ __device__ constexpr int ide_l(int i) { return i < 2 ? 1 : (i < 5 ? 2 :
 __host__ __device__ constexpr int ide_m(int i) { return i < 2 ? i : (i < 5 ? i - 2 : (i < 10 ? i - 5 : (i < 19 ? i - 10 : i - 19))); }
 
 
-// activation slice of the shader (steps): [0,64) bottleneck | [64,100) IDE | 100 bias(1|0) | 101 (dot|1)
+// activation slice of the shader (steps): [0,48) feature (hidden 32 | appearance 16) | [48,84) IDE | 84 bias(1|0) |
+// 85 (dot|1).  The 128-wide shader bottleneck (Dense(96 -> 128) WITHOUT activation, nerf.py:394-396) only feeds
+// linear layers -- SLF layer_0, the input part of SLF layer_bottleneck, integrated_brdf_layers_0 -- so the host
+// folds it into those (W' = W_b W[:128], b' = b + b_b W[:128], products in fp64): the layer itself and 16 k-steps of
+// each consumer disappear (1767 instead of 2123 MFMAs per tile), results equal up to fp32 rounding of the folded weights.
 constexpr int kShActSteps = 102;
-constexpr int kStepBias = 100;
-constexpr int kStepDot = 101;
+constexpr int kStepIde = 48;
+constexpr int kStepBias = 84;
+constexpr int kStepDot = 85;
 
 // fragment offsets of the shader's layers inside its weight stream (host: rc_api.hip, same order)
 struct ShaderFrags {
-  static constexpr int F_H = 0, F_S0 = F_H + 49 * 5, F_I0 = F_S0 + 101 * 8, F_I1 = F_I0 + 65 * 2, F_IO = F_I1 + 33 * 2,
+  static constexpr int F_H = 0, F_S0 = F_H + 49, F_I0 = F_S0 + 85 * 8, F_I1 = F_I0 + 49 * 2, F_IO = F_I1 + 33 * 2,
                        F_S1 = F_IO + 33, F_S2 = F_S1 + 65 * 4, F_SB = F_S2 + 65 * 4, F_SO = F_SB + 64 * 4, COUNT = F_SO + 65;
 };
 
@@ -225,32 +230,29 @@ struct ShaderConsts { float roughness_bias, irradiance_bias, ambient_bias, rgb_m
 struct ShadeOut { float rgb[3], ad[3], idf[3], is[3], tint[3]; };
 
 // The cache shader on one 32-point tile.  Expects act steps [0,49) = [hidden density feature (32,
-// accumulator order) | appearance features (16 natural pairs) | bias]; (nx,ny,nz) the shading normal
+// accumulator order) | appearance features (16 natural pairs) | bias] (the feature stays there until the IBRDF
+// chain has read it); (nx,ny,nz) the shading normal
 // and (vx,vy,vz) the view direction of this lane's point.  F0 = offset of the shader's fragments in
 // the kernel's weight stream of NF fragments.
 template <int F0, int NF>
 __device__ __forceinline__ ShadeOut shader_tile(const WStream& ws, float* act, int lane, int h, float nx, float ny, float nz,
                                                 float vx, float vy, float vz, const RcIdeTable* tb, const ShaderConsts& k) {
-  // ---- heads: bottleneck (4 tiles, linear) + small heads tile
+  // ---- small heads tile on the feature (the bottleneck is folded into its consumers, see kShActSteps)
   float rough, tint[3], ad[3], idf[3];
   {
-    f32x16 acc[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t) acc[t] = zero16();
-    mlp_layer<5, 49, F0 + ShaderFrags::F_H, NF>(ws, act, acc);
-    // heads tile, by accumulator register (same on both half-waves): 0 roughness, 1-3 tint,
-    // 4-6 ambient irradiance, 7-9 irradiance
-    rough = softplus(acc[4][0] + k.roughness_bias);                       // nerf.py:633-634
-    tint[0] = sigmoidf(acc[4][1]); tint[1] = sigmoidf(acc[4][2]); tint[2] = sigmoidf(acc[4][3]);   // :976
-    const float ar[3] = {acc[4][4], acc[4][5], acc[4][6]};
-    const float ir[3] = {acc[4][7], acc[4][8], acc[4][9]};
+    f32x16 acc[1];
+    acc[0] = zero16();
+    mlp_layer<1, 49, F0 + ShaderFrags::F_H, NF>(ws, act, acc);
+    // by accumulator register (same on both half-waves): 0 roughness, 1-3 tint, 4-6 ambient irradiance, 7-9 irradiance
+    rough = softplus(acc[0][0] + k.roughness_bias);                       // nerf.py:633-634
+    tint[0] = sigmoidf(acc[0][1]); tint[1] = sigmoidf(acc[0][2]); tint[2] = sigmoidf(acc[0][3]);   // :976
+    const float ar[3] = {acc[0][4], acc[0][5], acc[0][6]};
+    const float ir[3] = {acc[0][7], acc[0][8], acc[0][9]};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       ad[c] = fminf(fmaxf(softplus(ar[c] + k.ambient_bias), 0.0f), k.rgb_max);      // nerf.py:965-969
       idf[c] = fminf(fmaxf(softplus(ir[c] + k.irradiance_bias), 0.0f), k.rgb_max);  // nerf.py:1008-1012
     }
-    f32x16 bt[4] = {acc[0], acc[1], acc[2], acc[3]};
-    park<4, false>(bt, act, 0);
   }
   // ---- normals, n.(-v), reflection direction, IDE
   {
@@ -286,31 +288,31 @@ __device__ __forceinline__ ShadeOut shader_tile(const WStream& ws, float* act, i
         if (k <= l - m && ((l - m - k) & 1) == 0) poly = poly + zp[k] * tb->coef[i][k];
       }
       const float att = expf(-(0.5f * (float)(l * (l + 1))) * rough);
-      act[(64 + i) * 64] = (cpw[m] * poly) * att;
+      act[(kStepIde + i) * 64] = (cpw[m] * poly) * att;
     }
   }
-  // ---- SLF layer_0 (tiles 0-3) + input part of layer_bottleneck (tiles 4-7): one pass over
-  //      [bottleneck | IDE | bias]; results stay in registers while the IBRDF chain runs.
+  // ---- SLF layer_0 (tiles 0-3) + input part of layer_bottleneck (tiles 4-7), bottleneck folded in: one pass
+  //      over [feature | IDE | bias]; results stay in registers while the IBRDF chain runs.
   f32x16 s0[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) s0[t] = zero16();
-  mlp_layer<8, 101, F0 + ShaderFrags::F_S0, NF>(ws, act, s0);
-  // ---- integrated BRDF: (bottleneck, n.v) 129 -> 64 -> 64 -> 1 (nerf.py:461-482)
+  mlp_layer<8, 85, F0 + ShaderFrags::F_S0, NF>(ws, act, s0);
+  // ---- integrated BRDF: (bottleneck, n.v) 129 -> 64 -> 64 -> 1 (nerf.py:461-482), first layer on the feature
   float ibrdf;
   {
     f32x16 ib[2];
     ib[0] = zero16(); ib[1] = zero16();
-    mlp_layer<2, 64, F0 + ShaderFrags::F_I0, NF>(ws, act, ib);
-    mlp_layer<2, 1, F0 + ShaderFrags::F_I0 + 128, NF>(ws, act + kStepDot * 64, ib);   // (n.v | bias) step
-    // IDE is dead now: steps [64, 97) are scratch for the IBRDF tail
-    park<2, true>(ib, act, 64);
-    act[(64 + 32) * 64] = h == 0 ? 1.0f : 0.0f;
+    mlp_layer<2, 48, F0 + ShaderFrags::F_I0, NF>(ws, act, ib);
+    mlp_layer<2, 1, F0 + ShaderFrags::F_I0 + 96, NF>(ws, act + kStepDot * 64, ib);   // (n.v | bias) step
+    // IDE is dead now: steps [48, 81) are scratch for the IBRDF tail
+    park<2, true>(ib, act, 48);
+    act[(48 + 32) * 64] = h == 0 ? 1.0f : 0.0f;
     ib[0] = zero16(); ib[1] = zero16();
-    mlp_layer<2, 33, F0 + ShaderFrags::F_I1, NF>(ws, act + 64 * 64, ib);
-    park<2, true>(ib, act, 64);
+    mlp_layer<2, 33, F0 + ShaderFrags::F_I1, NF>(ws, act + 48 * 64, ib);
+    park<2, true>(ib, act, 48);
     f32x16 o[1];
     o[0] = zero16();
-    mlp_layer<1, 33, F0 + ShaderFrags::F_IO, NF>(ws, act + 64 * 64, o);
+    mlp_layer<1, 33, F0 + ShaderFrags::F_IO, NF>(ws, act + 48 * 64, o);
     ibrdf = sigmoidf(o[0][0] + 1.0986123f);     // + log(3), nerf.py:481
   }
   // ---- SLF trunk: layer_1, layer_2, layer_bottleneck (x part accumulates onto the input part)

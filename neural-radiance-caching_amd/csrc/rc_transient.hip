@@ -25,18 +25,21 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // shader: activation steps of a wave (32 samples)
 // ---------------------------------------------------------------------------------------------
-constexpr int kTAct = 117;
+// (the linear shader bottleneck is folded into its consumers on the host, as in the steady-state shader:
+// SLF layer_0 / layer_bottleneck input part, integrated_brdf_layers_0, brdf_layers_0 read the 96-wide feature)
+constexpr int kTAct = 101;
 constexpr int T_BIAS0 = 48;    // heads / irradiance-net bias step (1 | 0)
 constexpr int T_LENC = 49;     // [49, 57)  pos_enc(lights): 15 values + an unused slot
 constexpr int T_IRR = 57;      // [57, 90)  irradiance-net hidden layer (32 steps + bias)
-constexpr int T_IDE = 64;      // [64, 100) IDE of the reflection direction
-constexpr int T_WENC = 100;    // [100, 108) pos_enc(contract(lights)): 15 values + bias slot (= 1)
-constexpr int T_DOT = 108;     // (n.(-v) | 1)
-constexpr int T_BENC = 109;    // [109, 117) BRDF encoding: 15 values + bias slot (= 1)
+constexpr int T_IDE = 48;      // [48, 84)  IDE of the reflection direction (after the irradiance net is done)
+constexpr int T_WENC = 84;     // [84, 92)  pos_enc(contract(lights)): 15 values + bias slot (= 1)
+constexpr int T_DOT = 92;      // (n.(-v) | 1)
+constexpr int T_BENC = 93;     // [93, 101) BRDF encoding: 15 values + bias slot (= 1)
+constexpr int T_SCR = 48;      // [48, 81)  scratch of the IBRDF / BRDF tails (IDE and light encoding are dead then)
 
 struct TFrags {
-  static constexpr int F_H = 0, F_IR0 = F_H + 49 * 5, F_IR1 = F_IR0 + 57 * 2, F_S0 = F_IR1 + 33 * 2, F_I0 = F_S0 + 108 * 8,
-                       F_I1 = F_I0 + 65 * 2, F_IO = F_I1 + 33 * 2, F_B0 = F_IO + 33, F_B1 = F_B0 + 72 * 2, F_BO = F_B1 + 33 * 2,
+  static constexpr int F_H = 0, F_IR0 = F_H + 49, F_IR1 = F_IR0 + 57 * 2, F_S0 = F_IR1 + 33 * 2, F_I0 = F_S0 + 92 * 8,
+                       F_I1 = F_I0 + 49 * 2, F_IO = F_I1 + 33 * 2, F_B0 = F_IO + 33, F_B1 = F_B0 + 56 * 2, F_BO = F_B1 + 33 * 2,
                        F_S1 = F_BO + 33, F_S2 = F_S1 + 65 * 4, F_SB = F_S2 + 65 * 4, COUNT = F_SB + 64 * 4;
 };
 
@@ -94,11 +97,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_shader(RcTransShaderA
     pos_enc2(l3, e, 0.0f);
     stage16(act, T_LENC, h, e);
   }
-  // ---- heads: bottleneck (4 tiles, linear) + heads tile (0 roughness, 1-3 tint, 4-6 direct tint, 7-9 albedo)
-  f32x16 hd[5];
-#pragma unroll
-  for (int t = 0; t < 5; ++t) hd[t] = zero16();
-  mlp_layer<5, 49, TFrags::F_H, NF>(ws, act, hd);
+  // ---- heads tile (0 roughness, 1-3 tint, 4-6 direct tint, 7-9 albedo)
+  f32x16 hd[1];
+  hd[0] = zero16();
+  mlp_layer<1, 49, TFrags::F_H, NF>(ws, act, hd);
   // ---- irradiance trunk on [feature | pos_enc(lights)] (nerf.py:1781-1791): the inputs are still in place
   {
     f32x16 ir[2];
@@ -115,15 +117,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_shader(RcTransShaderA
         for (int r = 0; r < 16; ++r) a.irr_feat[(tile * 32 + t * 16 + r) * 64 + lane] = fmaxf(ir[t][r], 0.0f);
     }
   }
-  const float rough = softplus(hd[4][0] + a.roughness_bias);                   // nerf.py:633-634
-  const float tint[3] = {sigmoidf(hd[4][1]), sigmoidf(hd[4][2]), sigmoidf(hd[4][3])};          // nerf.py:1697
-  const float dtint[3] = {sigmoidf(hd[4][4]), sigmoidf(hd[4][5]), sigmoidf(hd[4][6])};         // nerf.py:1469
-  const float albedo[3] = {softplus(hd[4][7] + a.albedo_bias), softplus(hd[4][8] + a.albedo_bias),
-                           softplus(hd[4][9] + a.albedo_bias)};                                // nerf.py:1466-1468
-  {
-    f32x16 bt[4] = {hd[0], hd[1], hd[2], hd[3]};
-    park<4, false>(bt, act, 0);
-  }
+  const float rough = softplus(hd[0][0] + a.roughness_bias);                   // nerf.py:633-634
+  const float tint[3] = {sigmoidf(hd[0][1]), sigmoidf(hd[0][2]), sigmoidf(hd[0][3])};          // nerf.py:1697
+  const float dtint[3] = {sigmoidf(hd[0][4]), sigmoidf(hd[0][5]), sigmoidf(hd[0][6])};         // nerf.py:1469
+  const float albedo[3] = {softplus(hd[0][7] + a.albedo_bias), softplus(hd[0][8] + a.albedo_bias),
+                           softplus(hd[0][9] + a.albedo_bias)};                                // nerf.py:1466-1468
   // ---- geometry of this lane's sample
   const float mx = a.means[pc], my = a.means[a.n + pc], mz = a.means[2 * a.n + pc];
   const float nx = a.normals[pc], ny = a.normals[a.n + pc], nz = a.normals[2 * a.n + pc];
@@ -201,43 +199,43 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_shader(RcTransShaderA
       act[(T_IDE + i) * 64] = (cpw[m] * poly) * att;
     }
   }
-  // ---- SLF layer_0 (tiles 0-3) + input part of layer_bottleneck (tiles 4-7) over [bottleneck | IDE | lights]
+  // ---- SLF layer_0 (tiles 0-3) + input part of layer_bottleneck (tiles 4-7) over [feature | IDE | lights]
   f32x16 s0[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) s0[t] = zero16();
-  mlp_layer<8, 108, TFrags::F_S0, NF>(ws, act, s0);
-  // ---- integrated BRDF (nerf.py:461-482); scratch [64, 97)
+  mlp_layer<8, 92, TFrags::F_S0, NF>(ws, act, s0);
+  // ---- integrated BRDF (nerf.py:461-482)
   float ibrdf;
   {
     f32x16 ib[2];
     ib[0] = zero16(); ib[1] = zero16();
-    mlp_layer<2, 64, TFrags::F_I0, NF>(ws, act, ib);
-    mlp_layer<2, 1, TFrags::F_I0 + 128, NF>(ws, act + T_DOT * 64, ib);
-    park<2, true>(ib, act, 64);
-    act[(64 + 32) * 64] = h == 0 ? 1.0f : 0.0f;
+    mlp_layer<2, 48, TFrags::F_I0, NF>(ws, act, ib);
+    mlp_layer<2, 1, TFrags::F_I0 + 96, NF>(ws, act + T_DOT * 64, ib);
+    park<2, true>(ib, act, T_SCR);
+    act[(T_SCR + 32) * 64] = h == 0 ? 1.0f : 0.0f;
     ib[0] = zero16(); ib[1] = zero16();
-    mlp_layer<2, 33, TFrags::F_I1, NF>(ws, act + 64 * 64, ib);
-    park<2, true>(ib, act, 64);
+    mlp_layer<2, 33, TFrags::F_I1, NF>(ws, act + T_SCR * 64, ib);
+    park<2, true>(ib, act, T_SCR);
     f32x16 o[1];
     o[0] = zero16();
-    mlp_layer<1, 33, TFrags::F_IO, NF>(ws, act + 64 * 64, o);
+    mlp_layer<1, 33, TFrags::F_IO, NF>(ws, act + T_SCR * 64, o);
     ibrdf = sigmoidf(o[0][0] + 1.0986123f);
   }
-  // ---- BRDF towards the light (nerf.py:484-538): [bottleneck | enc(sorted dots, n.h)] -> 64 -> 64 -> 1
+  // ---- BRDF towards the light (nerf.py:484-538): [bottleneck | enc(sorted dots, n.h)] -> 64 -> 64 -> 1 (first layer folded)
   float lbrdf;
   {
     f32x16 b[2];
     b[0] = zero16(); b[1] = zero16();
-    mlp_layer<2, 64, TFrags::F_B0, NF>(ws, act, b);
-    mlp_layer<2, 8, TFrags::F_B0 + 128, NF>(ws, act + T_BENC * 64, b);
-    park<2, true>(b, act, 64);
-    act[(64 + 32) * 64] = h == 0 ? 1.0f : 0.0f;
+    mlp_layer<2, 48, TFrags::F_B0, NF>(ws, act, b);
+    mlp_layer<2, 8, TFrags::F_B0 + 96, NF>(ws, act + T_BENC * 64, b);
+    park<2, true>(b, act, T_SCR);
+    act[(T_SCR + 32) * 64] = h == 0 ? 1.0f : 0.0f;
     b[0] = zero16(); b[1] = zero16();
-    mlp_layer<2, 33, TFrags::F_B1, NF>(ws, act + 64 * 64, b);
-    park<2, true>(b, act, 64);
+    mlp_layer<2, 33, TFrags::F_B1, NF>(ws, act + T_SCR * 64, b);
+    park<2, true>(b, act, T_SCR);
     f32x16 o[1];
     o[0] = zero16();
-    mlp_layer<1, 33, TFrags::F_BO, NF>(ws, act + 64 * 64, o);
+    mlp_layer<1, 33, TFrags::F_BO, NF>(ws, act + T_SCR * 64, o);
     lbrdf = softplus(o[0][0] + a.brdf_bias);
     if (n_dot_l == 0.0f) lbrdf = 0.0f;                                        // nerf.py:1478-1481
   }
