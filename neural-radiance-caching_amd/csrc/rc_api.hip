@@ -275,6 +275,22 @@ Tile tile_by_reg(const std::vector<Col>& regs) {
   return tl;
 }
 
+// Fragments of dot_out (rc_dev_mlp.h): per output, per tile, per accumulator register the weight of the feature that
+// register holds on each half-wave; then one bias fragment per output.
+std::vector<float> pack_dot(const std::vector<Col>& outs, int ntiles) {
+  std::vector<float> v;
+  for (const Col& c : outs)
+    for (int t = 0; t < ntiles; ++t)
+      for (int r = 0; r < 16; ++r)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int row = acc_feat(t, r, lane >> 5) + c.row_off;
+          v.push_back((c.L && row < c.L->in) ? c.L->kernel[(size_t)row * c.L->out + c.col] : 0.0f);
+        }
+  for (const Col& c : outs)
+    for (int lane = 0; lane < 64; ++lane) v.push_back(c.L ? c.L->bias[c.col] : 0.0f);
+  return v;
+}
+
 std::vector<float> pack(const std::vector<Step>& steps, const std::vector<Tile>& tiles) {
   const size_t NT = tiles.size();
   std::vector<float> out(steps.size() * NT * 64, 0.0f);
@@ -373,18 +389,14 @@ int repack(rc_handle* h) {
     append(stream, pack(s, {tile_full(d1, 0), tile_full(d1, 1)}));
     std::vector<Col> regs = {Col{dout, 0}};
     if (dn) { regs.push_back(Col{dn, 0}); regs.push_back(Col{dn, 1}); regs.push_back(Col{dn, 2}); }
-    append(stream, pack(s, {tile_by_reg(regs)}));
+    append(stream, pack_dot(regs, 2));
     if (dn) {
-      // backward fragments for the analytic normals (last level): w_out in accumulator layout, W1^T, W0^T
+      // backward fragments for the analytic normals (last level): W1^T, W0^T (w_out is kept from the forward dot)
       HostLayer w1t, w0t;
       w1t.in = d1->out; w1t.out = d1->in; w1t.kernel.resize(d1->kernel.size()); w1t.bias.assign(w1t.out, 0.0f);
       for (int r = 0; r < d1->in; ++r) for (int c2 = 0; c2 < d1->out; ++c2) w1t.kernel[(size_t)c2 * w1t.out + r] = d1->kernel[(size_t)r * d1->out + c2];
       w0t.in = d0->out; w0t.out = d0->in; w0t.kernel.resize(d0->kernel.size()); w0t.bias.assign(w0t.out, 0.0f);
       for (int r = 0; r < d0->in; ++r) for (int c2 = 0; c2 < d0->out; ++c2) w0t.kernel[(size_t)c2 * w0t.out + r] = d0->kernel[(size_t)r * d0->out + c2];
-      std::vector<float> wo(32 * 64);
-      for (int t = 0; t < 2; ++t) for (int r = 0; r < 16; ++r) for (int lane = 0; lane < 64; ++lane)
-        wo[(size_t)(t * 16 + r) * 64 + lane] = dout->kernel[(size_t)acc_feat(t, r, lane >> 5) * dout->out + 0];
-      append(stream, wo);
       std::vector<Step> sb; steps_acc(sb, 2, 0);
       append(stream, pack(sb, {tile_full(&w1t, 0, 0, false), tile_full(&w1t, 1, 0, false)}));
       append(stream, pack(sb, {tile_full(&w0t, 0, 0, false)}));
@@ -455,7 +467,7 @@ int repack(rc_handle* h) {
     append(stream, pack(s, {tile_full(&i0f, 0), tile_full(&i0f, 1)}));
     s.clear(); steps_acc(s, 2, 0); step_bias(s);
     append(stream, pack(s, {tile_full(i1, 0), tile_full(i1, 1)}));
-    append(stream, pack(s, {tile_by_reg({Col{io, 0}})}));
+    append(stream, pack_dot({Col{io, 0}}, 2));
     // SLF trunk
     s.clear(); steps_acc(s, 4, 0); step_bias(s);
     append(stream, pack(s, {tile_full(l1, 0), tile_full(l1, 1), tile_full(l1, 2), tile_full(l1, 3)}));
@@ -463,7 +475,7 @@ int repack(rc_handle* h) {
     std::vector<Step> sb; steps_acc(sb, 4, 0);
     append(stream, pack(sb, {tile_full(lb, 0, 0, false), tile_full(lb, 1, 0, false), tile_full(lb, 2, 0, false),
                              tile_full(lb, 3, 0, false)}));
-    append(stream, pack(s, {tile_by_reg({Col{la, 0}, Col{la, 1}, Col{la, 2}})}));
+    append(stream, pack_dot({Col{la, 0}, Col{la, 1}, Col{la, 2}}, 4));
     fused_parts[3] = stream;
     int rc = upload(h, "shader", pad_stream(stream));
     if (rc) return rc;

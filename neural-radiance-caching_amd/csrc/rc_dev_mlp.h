@@ -174,6 +174,50 @@ __device__ __forceinline__ void park(const f32x16 (&acc)[NT], float* act, int ba
     }
 }
 
+// Output layers with a handful of rows (density + predicted normals, integrated BRDF, ambient rgb): in-register dot
+// products over the hidden activations as they sit in the accumulators (ReLU applied here), instead of a mostly
+// empty MFMA tile.  Fragments [FBASE, FBASE + NO * NT * 16 + NO): for output o, tile t, register r the weights
+// w_o[feature(t, r, half-wave)], then one fragment per output holding the bias on every lane.  PT point-tiles share
+// each weight read.  `keep` (optional, KEEP) returns the weights of output 0 (the backward pass of the analytic
+// normals starts from them).  Two partial sums per output (even / odd registers), the two half-waves added last.
+template <int PT, int NT, int NO, int FBASE, int NF, bool KEEP = false, int W = kWaves>
+__device__ __forceinline__ void dot_out(const WStream& w, const f32x16 (&hid)[PT][NT], float (&out)[PT][NO],
+                                        float (&keep)[KEEP ? NT * 16 : 1]) {
+  float part[PT][NO][2];
+#pragma unroll
+  for (int p = 0; p < PT; ++p)
+#pragma unroll
+    for (int o = 0; o < NO; ++o) { part[p][o][0] = 0.0f; part[p][o][1] = 0.0f; }
+#pragma unroll
+  for (int o = 0; o < NO; ++o)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float wv = ws_read<NF, W>(w, FBASE + (o * NT + t) * 16 + r);
+        if constexpr (KEEP) { if (o == 0) keep[t * 16 + r] = wv; }
+#pragma unroll
+        for (int p = 0; p < PT; ++p) part[p][o][r & 1] = __builtin_fmaf(fmaxf(hid[p][t][r], 0.0f), wv, part[p][o][r & 1]);
+      }
+#pragma unroll
+  for (int o = 0; o < NO; ++o) {
+    const float bias = ws_read<NF, W>(w, FBASE + NO * NT * 16 + o);
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+      float sum = part[p][o][0] + part[p][o][1];
+      sum = sum + __shfl_xor(sum, 32, 64);
+      out[p][o] = sum + bias;
+    }
+  }
+}
+template <int NT, int NO, int FBASE, int NF, bool KEEP = false, int W = kWaves>
+__device__ __forceinline__ void dot_out1(const WStream& w, const f32x16 (&hid)[NT], float (&out)[NO],
+                                         float (&keep)[KEEP ? NT * 16 : 1]) {
+  const f32x16 (&h1)[1][NT] = reinterpret_cast<const f32x16 (&)[1][NT]>(hid);
+  float (&o1)[1][NO] = reinterpret_cast<float (&)[1][NO]>(out);
+  dot_out<1, NT, NO, FBASE, NF, KEEP, W>(w, h1, o1, keep);
+}
+
 __device__ __forceinline__ float softplus(float x) {
   // jax.nn.softplus = logaddexp(x, 0) = max(x, 0) + log1p(exp(-|x|))
   return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));
@@ -223,7 +267,7 @@ constexpr int kStepDot = 85;
 // fragment offsets of the shader's layers inside its weight stream (host: rc_api.hip, same order)
 struct ShaderFrags {
   static constexpr int F_H = 0, F_S0 = F_H + 49, F_I0 = F_S0 + 85 * 8, F_I1 = F_I0 + 49 * 2, F_IO = F_I1 + 33 * 2,
-                       F_S1 = F_IO + 33, F_S2 = F_S1 + 65 * 4, F_SB = F_S2 + 65 * 4, F_SO = F_SB + 64 * 4, COUNT = F_SO + 65;
+                       F_S1 = F_IO + 33, F_S2 = F_S1 + 65 * 4, F_SB = F_S2 + 65 * 4, F_SO = F_SB + 64 * 4, COUNT = F_SO + 3 * 64 + 3;
 };
 
 struct ShaderConsts { float roughness_bias, irradiance_bias, ambient_bias, rgb_max, slf_ambient_bias; };
@@ -309,11 +353,9 @@ __device__ __forceinline__ ShadeOut shader_tile(const WStream& ws, float* act, i
     act[(48 + 32) * 64] = h == 0 ? 1.0f : 0.0f;
     ib[0] = zero16(); ib[1] = zero16();
     mlp_layer<2, 33, F0 + ShaderFrags::F_I1, NF>(ws, act + 48 * 64, ib);
-    park<2, true>(ib, act, 48);
-    f32x16 o[1];
-    o[0] = zero16();
-    mlp_layer<1, 33, F0 + ShaderFrags::F_IO, NF>(ws, act + 48 * 64, o);
-    ibrdf = sigmoidf(o[0][0] + 1.0986123f);     // + log(3), nerf.py:481
+    float o[1], nokeep[1];
+    dot_out1<2, 1, F0 + ShaderFrags::F_IO, NF>(ws, ib, o, nokeep);     // output_integrated_brdf_layer on relu(ib)
+    ibrdf = sigmoidf(o[0] + 1.0986123f);        // + log(3), nerf.py:481
   }
   // ---- SLF trunk: layer_1, layer_2, layer_bottleneck (x part accumulates onto the input part)
   float amb[3];
@@ -331,12 +373,10 @@ __device__ __forceinline__ ShadeOut shader_tile(const WStream& ws, float* act, i
     mlp_layer<4, 65, F0 + ShaderFrags::F_S2, NF>(ws, act, acc);
     park<4, true>(acc, act, 0);
     mlp_layer<4, 64, F0 + ShaderFrags::F_SB, NF>(ws, act, skip);
-    park<4, true>(skip, act, 0);
-    f32x16 o[1];
-    o[0] = zero16();
-    mlp_layer<1, 65, F0 + ShaderFrags::F_SO, NF>(ws, act, o);
+    float o[3], nokeep[1];
+    dot_out1<4, 3, F0 + ShaderFrags::F_SO, NF>(ws, skip, o, nokeep);   // output_ambient_rgb_layer on relu(layer_bottleneck)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) amb[c] = fmaxf(softplus(o[0][c] + k.slf_ambient_bias), 0.0f);   // slf.py:1053-1059
+    for (int c = 0; c < 3; ++c) amb[c] = fmaxf(softplus(o[c] + k.slf_ambient_bias), 0.0f);      // slf.py:1053-1059
   }
   ShadeOut o;
 #pragma unroll

@@ -31,12 +31,13 @@ constexpr int kJac = 49;                      // act steps [49, 97): d feature /
 
 // fragments of the fused weight stream
 template <int KS0> struct DensFrags {
-  static constexpr int D0 = 0, D1 = 2 * KS0, DO = 2 * KS0 + 66, WO = DO + 33, B1 = WO + 32, B0 = B1 + 64;
+  static constexpr int NO = KS0 == 17 ? 4 : 1;       // output rows: density (+ 3 predicted normals on the last level)
+  static constexpr int D0 = 0, D1 = 2 * KS0, DO = 2 * KS0 + 66, B1 = DO + NO * 33, B0 = B1 + 64, END = B0 + 32;
 };
 constexpr int F_L0 = 0;                              // K = 6: KS0 = 4
-constexpr int F_L1 = F_L0 + 2 * 4 + 99;              // K = 7: KS0 = 5
-constexpr int F_L2 = F_L1 + 2 * 5 + 99;              // K = 32: KS0 = 17, + 128 backward fragments
-constexpr int F_SH = F_L2 + 2 * 17 + 99 + 128;
+constexpr int F_L1 = F_L0 + DensFrags<4>::B1;        // K = 7: KS0 = 5
+constexpr int F_L2 = F_L1 + DensFrags<5>::B1;        // K = 32: KS0 = 17, with the 96 backward fragments
+constexpr int F_SH = F_L2 + DensFrags<17>::END;
 constexpr int NF = F_SH + ShaderFrags::COUNT;
 
 // Density MLP of a proposal level on 64 samples (two point-tiles); returns the raw density of
@@ -63,13 +64,10 @@ __device__ __forceinline__ float density_level64(const WStream& ws, float* act_w
 #pragma unroll
   for (int p = 0; p < 2; ++p) { acc[p][0] = zero16(); acc[p][1] = zero16(); }
   mlp_layer_pt<2, 2, 33, FB + FR::D1, NF>(ws, act, kTileStride, acc);
-#pragma unroll
-  for (int p = 0; p < 2; ++p) park<2, true>(acc[p], act + p * kTileStride, 0);
-  f32x16 out[2][1];
-  out[0][0] = zero16(); out[1][0] = zero16();
-  mlp_layer_pt<2, 1, 33, FB + FR::DO, NF>(ws, act, kTileStride, out);
-  // the output tile is duplicated on both half-waves: sample `lane` = (tile = lane >> 5, point lane & 31)
-  return tile == 0 ? out[0][0][0] : out[1][0][0];
+  float out[2][1], nokeep[1];
+  dot_out<2, 2, 1, FB + FR::DO, NF>(ws, acc, out, nokeep);       // output_density_layer on relu(acc), both point-tiles
+  // the dot product is complete on both half-waves: sample `lane` = (tile = lane >> 5, point lane & 31)
+  return tile == 0 ? out[0][0] : out[1][0];
 }
 
 #ifdef RC_STAMPS
@@ -295,11 +293,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
         for (int r = 0; r < 16; ++r) m1 |= (acc[t][r] > 0.0f ? 1u : 0u) << (t * 16 + r);
     }
     park<2, true>(acc, act, 0);               // hidden feature: stays at [0,32) for the shader
-    f32x16 out[1];
-    out[0] = zero16();
-    mlp_layer<1, 33, F_L2 + FR::DO, NF>(ws, act, out);
-    density = density_of(out[0][0], cx, cy, cz, a.grid[2].bbox);
-    npx = out[0][1]; npy = out[0][2]; npz = out[0][3];
+    float out[4], wout[GRAD ? 32 : 1];
+    dot_out1<2, 4, F_L2 + FR::DO, NF, GRAD>(ws, acc, out, wout);      // density + predicted normals on relu(acc)
+    density = density_of(out[0], cx, cy, cz, a.grid[2].bbox);
+    npx = out[1]; npy = out[2]; npz = out[3];
     neg_normalize(npx, npy, npz);
     if constexpr (GRAD) {
       // the backward pass borrows [0, 32): the hidden feature waits in registers meanwhile
@@ -308,10 +305,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
       for (int s = 0; s < 32; ++s) hid[s] = act[s * 64];
       float* bw = act;
 #pragma unroll
-      for (int s = 0; s < 32; ++s) {
-        const float wv = ws_read<NF>(ws, F_L2 + FR::WO + s);
-        bw[s * 64] = ((m1 >> s) & 1u) ? wv : 0.0f;
-      }
+      for (int s = 0; s < 32; ++s) bw[s * 64] = ((m1 >> s) & 1u) ? wout[s] : 0.0f;
       f32x16 g[2];
       g[0] = zero16(); g[1] = zero16();
       mlp_layer<2, 32, F_L2 + FR::B1, NF>(ws, bw, g);
@@ -358,7 +352,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
     } else {
       // the stream is consumed strictly in order: step the ring over the unused backward fragments
 #pragma unroll
-      for (int f = F_L2 + FR::WO; f < F_SH; ++f)
+      for (int f = F_L2 + FR::B1; f < F_SH; ++f)
         if (f % kChunk == 0) ws_advance<NF>(ws, f / kChunk);
     }
   }

@@ -38,8 +38,10 @@ template <int KS0, bool GRAD>   // KS0: k-steps of layer 0 including the bias st
 __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a) {
   __shared__ __attribute__((aligned(16))) float ring[kRingFloats];
   __shared__ float lds[kWaves][kDensActSteps * 64];
-  constexpr int F_D0 = 0, F_D1 = 2 * KS0, F_DO = 2 * KS0 + 66, F_WO = F_DO + 33, F_B1 = F_WO + 32,
-                F_B0 = F_B1 + 64, NF = GRAD ? F_B0 + 32 : F_WO;
+  // the last level (32 grid features) also predicts the normals: 4 output rows, otherwise 1
+  constexpr int NO = KS0 == 17 ? 4 : 1;
+  constexpr int F_D0 = 0, F_D1 = 2 * KS0, F_DO = 2 * KS0 + 66, F_B1 = F_DO + NO * 33, F_B0 = F_B1 + 64,
+                NF = GRAD ? F_B0 + 32 : F_B1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
   const int64_t p0 = tile * 32;
@@ -79,7 +81,6 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) m1 |= (acc[t][r] > 0.0f ? 1u : 0u) << (t * 16 + r);
   }
-  park<2, true>(acc, act, 0);
   if (a.last && a.hbuf && p0 < a.n) {
     // hidden feature handed to the shader in accumulator (= B operand) layout
     float* hb = a.hbuf + tile * (32 * 64) + lane;
@@ -89,9 +90,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
       for (int r = 0; r < 16; ++r) hb[(t * 16 + r) * 64] = fmaxf(acc[t][r], 0.0f);
   }
 
-  f32x16 out[1];
-  out[0] = zero16();
-  mlp_layer<1, 33, F_DO, NF>(ws, act, out);
+  float out[NO], wout[GRAD ? 32 : 1];
+  dot_out1<2, NO, F_DO, NF, GRAD>(ws, acc, out, wout);     // output_density_layer (+ pred_normals_layer) on relu(acc)
 
   float cx = 0.0f, cy = 0.0f, cz = 0.0f;   // contracted position
   float zx = 0.0f, zy = 0.0f, zz = 0.0f;   // x / radius
@@ -102,24 +102,21 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
   }
   if (h == 0 && valid) {
     // convert_raw_density (geometry.py:318-341)
-    const float raw = out[0][0];
+    const float raw = out[0];
     const bool inside = (cx > -a.bbox) & (cx < a.bbox) & (cy > -a.bbox) & (cy < a.bbox) & (cz > -a.bbox) & (cz < a.bbox);
     const float d = expf(fminf(fmaxf(raw + a.density_bias, -RC_FMAX), 70.0f));
     a.density[p] = inside ? d : 0.0f;
-    if (a.last && a.normals_pred) {
-      float gx = out[0][1], gy = out[0][2], gz = out[0][3];
+    if (NO == 4 && a.last && a.normals_pred) {
+      float gx = out[NO > 1 ? 1 : 0], gy = out[NO > 2 ? 2 : 0], gz = out[NO > 3 ? 3 : 0];
       neg_normalize(gx, gy, gz);
       a.normals_pred[p] = gx; a.normals_pred[a.n + p] = gy; a.normals_pred[2 * a.n + p] = gz;
     }
   }
 
   if constexpr (GRAD) {
-    // d raw / d h1 = w_out (accumulator-layout constant vector from the stream), masked by ReLU'(h1)
+    // d raw / d h1 = w_out (the accumulator-layout weights the forward dot product just used), masked by ReLU'(h1)
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-      const float wv = ws_read<NF>(ws, F_WO + s);
-      act[s * 64] = ((m1 >> s) & 1u) ? wv : 0.0f;
-    }
+    for (int s = 0; s < 32; ++s) act[s * 64] = ((m1 >> s) & 1u) ? wout[s] : 0.0f;
     f32x16 g[2];
     g[0] = zero16(); g[1] = zero16();
     mlp_layer<2, 32, F_B1, NF>(ws, act, g);            // W1 . (.)   (transposed layer, no bias)
