@@ -612,7 +612,7 @@ int ensure_workspace(rc_handle* h, int64_t n) {
   if ((rc = ws_alloc(h, "jac", 3 * 32 * np))) return rc;
   if ((rc = ws_alloc(h, "app", 32 * np))) return rc;
   if ((rc = ws_alloc(h, "shade", RC_SHADE_CH * np))) return rc;
-  if ((rc = ws_alloc(h, "debug", 20 * ((np + 31) / 32) + 64))) return rc;
+  if ((rc = ws_alloc(h, "debug", 32 * ((np + 31) / 32) + 64))) return rc;
   if ((rc = ws_alloc(h, "env_rgb", 3 * n))) return rc;
   if ((rc = ws_alloc(h, "rgb_noenv", 3 * n))) return rc;
   if ((rc = ws_alloc(h, "acc_ws", n))) return rc;

@@ -81,7 +81,7 @@ __device__ __forceinline__ float ws_read(const WStream& w, int f) {
 template <int NT, int KS, int FBASE, int NF, int SG = (NT >= 8 ? 1 : (NT >= 4 ? 2 : (NT >= 2 ? 4 : 8))), int W = kWaves>
 __device__ __forceinline__ void mlp_layer(const WStream& w, const float* act, f32x16 (&acc)[NT]) {
   constexpr int NG = (KS + SG - 1) / SG;
-  float a[2][SG][NT], b[2][SG];
+  float a[3][SG][NT], b[3][SG];
   auto load = [&](int g, int buf) {
 #pragma unroll
     for (int d = 0; d < SG; ++d) {
@@ -107,12 +107,16 @@ __device__ __forceinline__ void mlp_layer(const WStream& w, const float* act, f3
       }
     }
   };
+  // operands are fetched TWO groups ahead (three register sets): a chunk seam (barrier + LDS-DMA issue) inside
+  // load(g + 2) then sits between groups whose operands are already in registers, and the LDS latency of the
+  // new reads has a whole group of MFMAs to hide behind
   load(0, 0);
+  if (NG > 1) load(1, 1);
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    if (g + 1 < NG) load(g + 1, (g + 1) & 1);
+    if (g + 2 < NG) load(g + 2, (g + 2) % 3);
     __builtin_amdgcn_sched_barrier(0);
-    comp(g, g & 1);
+    comp(g, g % 3);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -123,7 +127,7 @@ __device__ __forceinline__ void mlp_layer(const WStream& w, const float* act, f3
 template <int PT, int NT, int KS, int FBASE, int NF, int SG = (NT * PT >= 8 ? 1 : (NT * PT >= 4 ? 2 : 4)), int W = kWaves>
 __device__ __forceinline__ void mlp_layer_pt(const WStream& w, const float* act, int tile_stride, f32x16 (&acc)[PT][NT]) {
   constexpr int NG = (KS + SG - 1) / SG;
-  float a[2][SG][NT], b[2][SG][PT];
+  float a[3][SG][NT], b[3][SG][PT];
   auto load = [&](int g, int buf) {
 #pragma unroll
     for (int d = 0; d < SG; ++d) {
@@ -153,11 +157,12 @@ __device__ __forceinline__ void mlp_layer_pt(const WStream& w, const float* act,
     }
   };
   load(0, 0);
+  if (NG > 1) load(1, 1);
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    if (g + 1 < NG) load(g + 1, (g + 1) & 1);
+    if (g + 2 < NG) load(g + 2, (g + 2) % 3);
     __builtin_amdgcn_sched_barrier(0);
-    comp(g, g & 1);
+    comp(g, g % 3);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -278,9 +283,16 @@ struct ShadeOut { float rgb[3], ad[3], idf[3], is[3], tint[3]; };
 // chain has read it); (nx,ny,nz) the shading normal
 // and (vx,vy,vz) the view direction of this lane's point.  F0 = offset of the shader's fragments in
 // the kernel's weight stream of NF fragments.
+#ifdef RC_STAMPS
+#define RC_TSTAMP(i) do { if (st) { __builtin_amdgcn_sched_barrier(0); st[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define RC_TSTAMP(i) do { } while (0)
+#endif
 template <int F0, int NF>
 __device__ __forceinline__ ShadeOut shader_tile(const WStream& ws, float* act, int lane, int h, float nx, float ny, float nz,
-                                                float vx, float vy, float vz, const RcIdeTable* tb, const ShaderConsts& k) {
+                                                float vx, float vy, float vz, const RcIdeTable* tb, const ShaderConsts& k,
+                                                unsigned long long* st = nullptr) {
+  RC_TSTAMP(0);
   // ---- small heads tile on the feature (the bottleneck is folded into its consumers, see kShActSteps)
   float rough, tint[3], ad[3], idf[3];
   {
@@ -298,6 +310,7 @@ __device__ __forceinline__ ShadeOut shader_tile(const WStream& ws, float* act, i
       idf[c] = fminf(fmaxf(softplus(ir[c] + k.irradiance_bias), 0.0f), k.rgb_max);  // nerf.py:1008-1012
     }
   }
+  RC_TSTAMP(1);
   // ---- normals, n.(-v), reflection direction, IDE
   {
     const float dotp = nx * (-vx) + ny * (-vy) + nz * (-vz);        // nerf.py:474
@@ -335,12 +348,14 @@ __device__ __forceinline__ ShadeOut shader_tile(const WStream& ws, float* act, i
       act[(kStepIde + i) * 64] = (cpw[m] * poly) * att;
     }
   }
+  RC_TSTAMP(2);
   // ---- SLF layer_0 (tiles 0-3) + input part of layer_bottleneck (tiles 4-7), bottleneck folded in: one pass
   //      over [feature | IDE | bias]; results stay in registers while the IBRDF chain runs.
   f32x16 s0[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) s0[t] = zero16();
   mlp_layer<8, 85, F0 + ShaderFrags::F_S0, NF>(ws, act, s0);
+  RC_TSTAMP(3);
   // ---- integrated BRDF: (bottleneck, n.v) 129 -> 64 -> 64 -> 1 (nerf.py:461-482), first layer on the feature
   float ibrdf;
   {
@@ -357,6 +372,7 @@ __device__ __forceinline__ ShadeOut shader_tile(const WStream& ws, float* act, i
     dot_out1<2, 1, F0 + ShaderFrags::F_IO, NF>(ws, ib, o, nokeep);     // output_integrated_brdf_layer on relu(ib)
     ibrdf = sigmoidf(o[0] + 1.0986123f);        // + log(3), nerf.py:481
   }
+  RC_TSTAMP(4);
   // ---- SLF trunk: layer_1, layer_2, layer_bottleneck (x part accumulates onto the input part)
   float amb[3];
   {
@@ -370,14 +386,18 @@ __device__ __forceinline__ ShadeOut shader_tile(const WStream& ws, float* act, i
     park<4, true>(acc, act, 0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = zero16();
+    RC_TSTAMP(5);
     mlp_layer<4, 65, F0 + ShaderFrags::F_S2, NF>(ws, act, acc);
     park<4, true>(acc, act, 0);
+    RC_TSTAMP(6);
     mlp_layer<4, 64, F0 + ShaderFrags::F_SB, NF>(ws, act, skip);
+    RC_TSTAMP(7);
     float o[3], nokeep[1];
     dot_out1<4, 3, F0 + ShaderFrags::F_SO, NF>(ws, skip, o, nokeep);   // output_ambient_rgb_layer on relu(layer_bottleneck)
 #pragma unroll
     for (int c = 0; c < 3; ++c) amb[c] = fmaxf(softplus(o[c] + k.slf_ambient_bias), 0.0f);      // slf.py:1053-1059
   }
+  RC_TSTAMP(8);
   ShadeOut o;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {

@@ -203,14 +203,18 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_shader(RcShaderArgs a) {
   const ShaderConsts kc{a.roughness_bias, a.irradiance_bias, a.ambient_bias, a.rgb_max, a.slf_ambient_bias};
   const ShadeOut so = shader_tile<0, NF>(ws, act, lane, h, a.normals_pred[q], a.normals_pred[a.n_src + q],
                                         a.normals_pred[2 * a.n_src + q], a.viewdirs[3 * ray], a.viewdirs[3 * ray + 1],
-                                        a.viewdirs[3 * ray + 2], reinterpret_cast<const RcIdeTable*>(a.ide_coef), kc);
-  RC_STAMP(6);
+                                        a.viewdirs[3 * ray + 2], reinterpret_cast<const RcIdeTable*>(a.ide_coef), kc
+#ifdef RC_STAMPS
+                                        , stamps + 2
+#endif
+                                        );
+  RC_STAMP(11);
 #ifdef RC_STAMPS
   if (lane == 0 && a.debug) {
     const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long* d = reinterpret_cast<unsigned long long*>(a.debug) + tile * 10;
-    for (int i = 0; i < 7; ++i) d[i] = stamps[i < 2 ? i : 6];
-    d[7] = rt0; d[8] = rt1;
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(a.debug) + tile * 16;
+    for (int i = 0; i < 12; ++i) d[i] = stamps[i];
+    d[12] = rt0; d[13] = rt1;
   }
 #endif
   if (h == 0 && valid) {
