@@ -462,12 +462,11 @@ int rc_fused_stream_offsets(int* l0, int* l1, int* l2, int* sh) {
 
 void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream) {
   if (L.n <= 0) return;
-  static bool prepared = false;
+  static std::atomic<uint64_t> prepared{0};
   const int lds = (kRingFloats + kWaves * (kShActSteps * 64 + kScratch)) * (int)sizeof(float);
-  if (!prepared) {
+  if (rc_first_use_on_device(prepared)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    prepared = true;
   }
   RcFusedArgs a{};
   a.origins = L.rays.origins; a.directions = L.rays.directions; a.viewdirs = L.rays.viewdirs; a.near = L.rays.near;

@@ -1,5 +1,6 @@
 // Internal declarations shared by the gfx950 kernels and the C-ABI host (rc_api.hip).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -294,3 +295,13 @@ struct RcCastArgs {
   float* lights; float* near; float* far;
 };
 void rc_launch_cast_rays(const RcCastArgs& a, hipStream_t stream);
+
+
+// Kernel attributes (dynamic-LDS limit) are per device: true the first time the calling thread's current device
+// shows up for this `mask` (one mask per kernel), so a process driving several GPUs sets them on each.
+inline bool rc_first_use_on_device(std::atomic<uint64_t>& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  return (mask.fetch_or(bit) & bit) == 0;
+}

@@ -326,11 +326,10 @@ int rc_weight_chunk_floats() { return kChunk * 64; }
 
 // The shader's per-wave activation slices exceed the default 64 KiB dynamic-LDS limit.
 void rc_shader_prepare() {
-  static bool done = false;
-  if (done) return;
+  static std::atomic<uint64_t> done{0};
+  if (!rc_first_use_on_device(done)) return;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_shader),
                             hipFuncAttributeMaxDynamicSharedMemorySize, rc_shader_lds_bytes());
-  done = true;
 }
 
 void rc_launch_shader(const RcShaderArgs& a, hipStream_t stream) {
@@ -342,11 +341,10 @@ void rc_launch_shader(const RcShaderArgs& a, hipStream_t stream) {
 
 void rc_launch_envmap(const RcEnvMapArgs& a, hipStream_t stream) {
   if (a.n <= 0) return;
-  static bool prepared = false;
+  static std::atomic<uint64_t> prepared{0};
   const int lds = (kRingFloats + kEnvWaves * kEnvActSteps * 64) * (int)sizeof(float);
-  if (!prepared) {
+  if (rc_first_use_on_device(prepared)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_envmap), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    prepared = true;
   }
   const int64_t tiles = (a.n + 31) / 32;
   dim3 grid((unsigned)((tiles + kEnvWaves - 1) / kEnvWaves)), block(kEnvWaves * 64);

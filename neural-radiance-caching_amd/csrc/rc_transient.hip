@@ -667,11 +667,10 @@ int rc_transient_bins_frags() { return kBinFrags; }
 
 void rc_launch_transient_shader(const RcTransShaderArgs& a, hipStream_t stream) {
   if (a.n <= 0) return;
-  static bool prepared = false;
+  static std::atomic<uint64_t> prepared{0};
   const int lds = (kRingFloats + kWaves * kTAct * 64) * (int)sizeof(float);
-  if (!prepared) {
+  if (rc_first_use_on_device(prepared)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_transient_shader), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    prepared = true;
   }
   const int64_t ntiles = (a.n + 31) / 32;
   hipLaunchKernelGGL(k_transient_shader, dim3((unsigned)((ntiles + kWaves - 1) / kWaves)), dim3(kWaves * 64), lds, stream, a);
@@ -679,11 +678,10 @@ void rc_launch_transient_shader(const RcTransShaderArgs& a, hipStream_t stream) 
 
 void rc_launch_transient_bins(const RcTransBinsArgs& a, hipStream_t stream) {
   if (a.n_rays <= 0) return;
-  static bool prepared = false;
+  static std::atomic<uint64_t> prepared{0};
   const int lds = (kRingFloats + kWaves * kWaveLds) * (int)sizeof(float);
-  if (!prepared) {
+  if (rc_first_use_on_device(prepared)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_transient_bins), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    prepared = true;
   }
   hipLaunchKernelGGL(k_transient_bins, dim3((unsigned)((a.n_rays + kWaves - 1) / kWaves)), dim3(kWaves * 64), lds, stream, a);
 }

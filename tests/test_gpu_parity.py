@@ -689,3 +689,37 @@ def test_transient_occlusions_shadow_rays_vs_oracle():
     for k in ("occ", "direct_rgb", "integrated_rgb", "diffuse_rgb", "specular_rgb"):
         assert np.abs(out[k][same] - r[k][same]).max() <= 2e-4 * max(1.0, np.abs(r[k]).max()), k
     assert np.abs(out["transient_indirect_viz"] - r["transient_indirect_viz"]).max() <= 5e-5     # not touched by the shadows
+
+
+# ---------------------------------------------------------------------------------------------
+# sizes beyond one workgroup per compute unit, empty / tiny transient batches
+# ---------------------------------------------------------------------------------------------
+def test_large_ragged_batch_fused_equals_staged(rc):
+    """18 433 rays (4609 workgroups, the last one with a single live wave): every output of the fused kernel
+    bitwise equal to the launch-per-stage plan, and the oracle on a strided subset of the rays."""
+    n = 18433
+    out = _render(rc, n, 4)
+    st = _render(rc, n, 4, fused=False)
+    for k, v in out.items():
+        assert np.array_equal(st[k], v), k
+    assert np.all(np.isfinite(out["rgb"])) and out["acc"].min() >= 0 and out["acc"].max() <= 1 + 1e-6
+    sub = np.arange(0, n, 257)
+    rays = nrc_amd.synthetic_rays(n)
+    f = {k: np.asarray(v)[sub] for k, v in rays.hot_fields().items()}
+    jit = [j[sub] for j in common.jitters(n, seed=4)]
+    from oracle import cache_ref
+    ref = cache_ref.cache_forward(common.weights_torch(), nrc_amd.hotdog_config(), common.rays_dict_torch(f),
+                                  [torch.from_numpy(j) for j in jit], want_grad_normals=False)["render"]
+    assert np.abs(out["rgb"][sub] - ref["rgb"].numpy()).max() <= RGB_TOL
+    assert np.abs(out["acc"][sub] - ref["acc"].numpy()).max() <= RGB_TOL
+
+
+def test_transient_empty_and_single_ray(rc_transient):
+    rays = nrc_amd.synthetic_transient_rays(4)
+    f0 = {k: np.asarray(v)[:0] for k, v in rays.hot_fields().items()}
+    out = rc_transient.render_transient(f0, None, outputs=["rgb", "acc"])
+    assert tuple(out["rgb"].shape) == (0, 700, 3) and tuple(out["acc"].shape) == (0,)
+    one = _render_transient(rc_transient, 1)
+    ref = common.oracle_transient(1)["render"]
+    assert np.abs(one["rgb"] - ref["rgb"].numpy()).max() <= 2e-5
+    assert np.abs(one["integrated_rgb"] - ref["integrated_rgb"].numpy()).max() <= RGB_TOL * max(1.0, float(ref["integrated_rgb"].abs().max()))
