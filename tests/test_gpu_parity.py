@@ -723,3 +723,22 @@ def test_transient_empty_and_single_ray(rc_transient):
     ref = common.oracle_transient(1)["render"]
     assert np.abs(one["rgb"] - ref["rgb"].numpy()).max() <= 2e-5
     assert np.abs(one["integrated_rgb"] - ref["integrated_rgb"].numpy()).max() <= RGB_TOL * max(1.0, float(ref["integrated_rgb"].abs().max()))
+
+
+def test_transient_render_image_keys_and_shapes():
+    """models.render_image with the time-resolved model: `rgb` is [H, W, 700, 3]; every `transient*` key except the two
+    *_viz ones is dropped (internal/models.py:2403, 2459-2472); chunks are edge-padded."""
+    from nrc_amd import model as M
+    cfg = nrc_amd.cornell_transient_config(render_chunk_size=16)
+    m = M.Model(cfg, 0)
+    m.load_variables(common.weights_transient_np())
+    H, W = 5, 6
+    flat = nrc_amd.synthetic_transient_rays(H * W)
+    rays = flat.tree_map(lambda r: np.asarray(r).reshape((H, W) + np.asarray(r).shape[1:]))
+    img, _ = M.render_image(M.create_render_fn(m), None, rays, cfg, ("cache",), verbose=False)
+    assert img["rgb"].shape == (H, W, 700, 3) and img["integrated_rgb"].shape == (H, W, 3) and img["acc"].shape == (H, W)
+    assert "transient_direct_viz" in img and "transient_indirect_viz" in img
+    assert not any(("transient" in k) and k not in ("transient_direct_viz", "transient_indirect_viz") for k in img)
+    # chunk 0 (16 rays) of the image == the same 16 rays rendered directly
+    direct = m.rc.render_transient({k: np.asarray(v)[:16] for k, v in flat.hot_fields().items()}, None, outputs=["rgb"])
+    assert np.array_equal(img["rgb"].reshape(H * W, 700, 3)[:16], direct["rgb"].cpu().numpy())
