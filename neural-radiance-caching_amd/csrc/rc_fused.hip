@@ -316,24 +316,21 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
       f32x16 gf[1];
       gf[0] = zero16();
       mlp_layer<1, 32, F_L2 + FR::B0, NF>(ws, bw, gf);
-      // d raw / d feature i = acc_feat(0, r, h) sits on lane (j, h); half-wave 0 owns the Jacobian, so it
-      // fetches the other half's 16 features with a cross-half shuffle
-      // (two partial sums, one per half-wave's features, added last: the order k_density_mlp uses)
-      float g0[3] = {0.0f, 0.0f, 0.0f}, g1[3] = {0.0f, 0.0f, 0.0f};
+      // d raw / d feature i = acc_feat(0, r, h) sits on lane (j, h): each half-wave contracts ITS 16 features with the
+      // Jacobian rows parked in LDS, the two partial sums are added last (the order k_density_mlp uses)
+      float gp[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float mine = gf[0][r];
-        const float other = __shfl_xor(mine, 32, 64);
-        const int i_own = (r & 3) + 8 * (r >> 2), i_oth = i_own + 4;     // features of half 0 / half 1
-        if (h == 0) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
-          for (int ax = 0; ax < 3; ++ax) {
-            g0[ax] += mine * jac_at(ax * 32 + i_own);
-            g1[ax] += other * jac_at(ax * 32 + i_oth);
-          }
-        }
+        for (int ax = 0; ax < 3; ++ax) gp[ax] += gf[0][r] * jac_at(ax * 32 + i);
       }
-      const float gw[3] = {g0[0] + g1[0], g0[1] + g1[1], g0[2] + g1[2]};
+      float gw[3];
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        const float oth = __shfl_xor(gp[ax], 32, 64);
+        gw[ax] = h == 0 ? gp[ax] + oth : oth + gp[ax];        // half 0's partial first on both halves
+      }
 #pragma unroll
       for (int s = 0; s < 32; ++s) act[s * 64] = hid[s];
       const float msq = zx * zx + zy * zy + zz * zz;
