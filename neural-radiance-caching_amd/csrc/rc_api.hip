@@ -508,6 +508,19 @@ int repack(rc_handle* h) {
     if (ok) {
       int rc = upload(h, "fused", pad_stream(stream));
       if (rc) return rc;
+      // level-2 density + appearance tables interleaved entry by entry (same index in both grids): [dens 4 | app 4]
+      for (int l = 0; l < h->grids[2].dev.num_levels; ++l) {
+        const size_t entries = h->grids[2].dev.lvl[l].entries;
+        DevBuf& b = h->packs["pair_" + std::to_string(l)];
+        const size_t bytes = entries * 8 * sizeof(float);
+        if (b.bytes != bytes) {
+          if (b.p) RC_HIP(h, hipFree(b.p));
+          RC_HIP(h, hipMalloc((void**)&b.p, bytes));
+          b.bytes = bytes;
+        }
+        RC_HIP(h, hipMemcpy2D(b.p, 32, h->grids[2].dev.lvl[l].table, 16, 16, entries, hipMemcpyDeviceToDevice));
+        RC_HIP(h, hipMemcpy2D(b.p + 4, 32, h->grids[3].dev.lvl[l].table, 16, 16, entries, hipMemcpyDeviceToDevice));
+      }
     }
   }
   {
@@ -769,6 +782,7 @@ int rc_load_weights(rc_handle* h, const rc_tensor_desc* descs, int32_t n) {
         RC_HIP(h, hipMemcpy(b.p, d.data, bytes, d.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
         gs.dev.lvl[l].table = b.p;
         gs.loaded[l] = true;
+        h->packed_dirty = true;          // derived device copies (interleaved level-2 tables) follow the tables
         handled = true;
         break;
       }
@@ -923,6 +937,7 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     F.rays = A.rays; F.n = n;
     for (int l = 0; l < 3; ++l) { F.jitter[l] = rnd ? rnd->jitter[l] : nullptr; F.num_samples[l] = c.num_samples[l]; }
     for (int g = 0; g < 4; ++g) F.grid[g] = &h->grids[g].dev;
+    for (int l = 0; l < h->grids[2].dev.num_levels; ++l) F.pair_table[l] = h->packs["pair_" + std::to_string(l)].p;
     F.wstream = h->packs["fused"].p; F.ide_coef = h->ide_table.p;
     F.anneal = c.anneal; F.padding = c.resample_padding; F.density_bias = c.density_bias;
     F.contract_radius = c.contract_radius; F.bg = c.bg_intensity;

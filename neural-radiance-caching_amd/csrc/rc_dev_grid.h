@@ -59,7 +59,9 @@ template <int F> struct Corners { Vec<F> val[8]; float cw[3]; uint32_t zero_mask
 __device__ __forceinline__ float unit_box(float bbox, float x) { return (x - (-bbox)) / (bbox - (-bbox)); }
 
 // POW2: the caller guarantees power-of-two hash tables (mask != 0): no modulo path.
-template <int F, bool POW2 = false>
+// STRIDE: distance between consecutive entries in units of F floats (2 for the interleaved [density | appearance]
+// tables of the fused kernel, where `table` already points at this lane's half of an entry pair).
+template <int F, bool POW2 = false, int STRIDE = 1>
 __device__ __forceinline__ void grid_fetch(const float* __restrict__ table, int size, uint32_t mask, uint32_t entries,
                                            bool dense, float x01, float y01, float z01, Corners<F>& C) {
   const float N = (float)size;
@@ -99,7 +101,7 @@ __device__ __forceinline__ void grid_fetch(const float* __restrict__ table, int 
       const bool zero = out[0][b0] | out[1][b1] | out[2][b2];
       const uint32_t idx = zero ? 0u : term[2][b2] + term[1][b1] + term[0][b0];
       C.zero_mask |= (zero ? 1u : 0u) << c;
-      C.val[c] = load_entry<F>(table, idx);
+      C.val[c] = load_entry<F>(table, idx * STRIDE);
     }
   } else {
     const float loc[3] = {cx - 0.5f, cy - 0.5f, cz - 0.5f};     // grid_utils.py:61
@@ -121,7 +123,7 @@ __device__ __forceinline__ void grid_fetch(const float* __restrict__ table, int 
       const int b0 = (c >> 2) & 1, b1 = (c >> 1) & 1, b2 = c & 1;
       const uint32_t hsh = hx[b0] ^ hy[b1] ^ hz[b2];
       const uint32_t idx = (POW2 || mask) ? (hsh & mask) : (hsh % entries);
-      C.val[c] = load_entry<F>(table, idx);
+      C.val[c] = load_entry<F>(table, idx * STRIDE);
     }
   }
 }

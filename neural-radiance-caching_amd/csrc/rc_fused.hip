@@ -87,6 +87,7 @@ struct RcFusedArgs {
   int64_t n;
   const float* jitter[3];
   RcGridDev grid[4];
+  const float* pair_table[RC_MAX_GRID_LEVELS];
   const float* wstream; const float* ide_coef;
   USpec us[3];
   float anneal, padding, density_bias, contract_radius, bg;
@@ -232,9 +233,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int l = half * 4 + q;
-        // level geometry is identical for the two grids (checked on the host): only the table differs per half-wave
+        // level geometry is identical for the two grids (checked on the host) and so is the entry index: the host keeps
+        // a copy of the two tables interleaved entry by entry ([density 16 B | appearance 16 B]), so the two half-waves
+        // of a point read the two halves of ONE 32-byte pair -- half the cache-line requests and sector traffic
         const RcGridLevel& L = a.grid[2].lvl[l];
-        grid_fetch<4, true>(h == 0 ? L.table : a.grid[3].lvl[l].table, L.size, L.mask, 0u, L.dense != 0, ux, uy, uz, C[q]);
+        grid_fetch<4, true, 2>(a.pair_table[l] + 4 * h, L.size, L.mask, 0u, L.dense != 0, ux, uy, uz, C[q]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -470,6 +473,7 @@ void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream) {
   a.far = L.rays.far; a.lights = L.rays.lights; a.n = L.n;
   for (int l = 0; l < 3; ++l) { a.jitter[l] = L.jitter[l]; a.us[l] = make_uspec(L.num_samples[l], L.jitter[l] != nullptr); }
   for (int g = 0; g < 4; ++g) a.grid[g] = *L.grid[g];
+  for (int l = 0; l < RC_MAX_GRID_LEVELS; ++l) a.pair_table[l] = L.pair_table[l];
   a.wstream = L.wstream; a.ide_coef = L.ide_coef;
   a.anneal = L.anneal; a.padding = L.padding; a.density_bias = L.density_bias; a.contract_radius = L.contract_radius; a.bg = L.bg;
   for (int i = 0; i < 3; ++i) a.pct[i] = L.pct[i];

@@ -223,6 +223,7 @@ struct RcFusedLaunch {
   rc_rays rays; int64_t n;
   const float* jitter[3]; int32_t num_samples[3];
   const RcGridDev* grid[4];            // proposal 0, 1, 2 + appearance
+  const float* pair_table[RC_MAX_GRID_LEVELS];   // level-2 density and appearance tables interleaved entry by entry
   const float* wstream;                // [density MLP 0 | 1 | 2 (+ backward) | shader], see rc_fused_stream_offsets
   const float* ide_coef;
   float anneal, padding, density_bias, contract_radius, bg; float pct[3];
