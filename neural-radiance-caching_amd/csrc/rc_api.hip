@@ -510,6 +510,7 @@ int repack(rc_handle* h) {
       if (rc) return rc;
       // level-2 density + appearance tables interleaved entry by entry (same index in both grids): [dens 4 | app 4]
       for (int l = 0; l < h->grids[2].dev.num_levels; ++l) {
+        if (h->grids[2].dev.lvl[l].dense) continue;          // dense levels: cell tables below
         const size_t entries = h->grids[2].dev.lvl[l].entries;
         DevBuf& b = h->packs["pair_" + std::to_string(l)];
         const size_t bytes = entries * 8 * sizeof(float);
@@ -521,6 +522,34 @@ int repack(rc_handle* h) {
         RC_HIP(h, hipMemcpy2D(b.p, 32, h->grids[2].dev.lvl[l].table, 16, 16, entries, hipMemcpyDeviceToDevice));
         RC_HIP(h, hipMemcpy2D(b.p + 4, 32, h->grids[3].dev.lvl[l].table, 16, 16, entries, hipMemcpyDeviceToDevice));
       }
+      // dense levels as cell tables (the 8 corners of every cell of the zero-padded volume side by side):
+      // proposal grids 0 / 1: 8 floats per cell; level-2 pair: 8 x [density 4 | appearance 4] per cell
+      auto cells = [&](const std::string& key, size_t floats, float** out) -> int {
+        DevBuf& b = h->packs[key];
+        if (b.bytes != floats * sizeof(float)) {
+          if (b.p) RC_HIP(h, hipFree(b.p));
+          RC_HIP(h, hipMalloc((void**)&b.p, floats * sizeof(float)));
+          b.bytes = floats * sizeof(float);
+        }
+        *out = b.p;
+        return RC_OK;
+      };
+      for (int g = 0; g < 3; ++g)
+        for (int l = 0; l < h->grids[g].dev.num_levels; ++l) {
+          const RcGridLevel& L = h->grids[g].dev.lvl[l];
+          if (!L.dense) continue;
+          const size_t ncell = (size_t)(L.size + 3) * (L.size + 3) * (L.size + 3);
+          float* dst = nullptr;
+          if (g < 2) {
+            if ((rc = cells("cell" + std::to_string(g) + "_" + std::to_string(l), ncell * 8, &dst))) return rc;
+            rc_launch_build_cells(L.table, L.size, 1, dst, 1, 0, nullptr);
+          } else {
+            if ((rc = cells("pair_" + std::to_string(l), ncell * 64, &dst))) return rc;      // replaces the flat pair table
+            rc_launch_build_cells(L.table, L.size, 4, dst, 8, 0, nullptr);
+            rc_launch_build_cells(h->grids[3].dev.lvl[l].table, L.size, 4, dst, 8, 4, nullptr);
+          }
+        }
+      RC_HIP(h, hipDeviceSynchronize());
     }
   }
   {
@@ -938,6 +967,9 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     for (int l = 0; l < 3; ++l) { F.jitter[l] = rnd ? rnd->jitter[l] : nullptr; F.num_samples[l] = c.num_samples[l]; }
     for (int g = 0; g < 4; ++g) F.grid[g] = &h->grids[g].dev;
     for (int l = 0; l < h->grids[2].dev.num_levels; ++l) F.pair_table[l] = h->packs["pair_" + std::to_string(l)].p;
+    for (int g = 0; g < 2; ++g)
+      for (int l = 0; l < h->grids[g].dev.num_levels; ++l)
+        F.cell_table[g][l] = h->grids[g].dev.lvl[l].dense ? h->packs["cell" + std::to_string(g) + "_" + std::to_string(l)].p : nullptr;
     F.wstream = h->packs["fused"].p; F.ide_coef = h->ide_table.p;
     F.anneal = c.anneal; F.padding = c.resample_padding; F.density_bias = c.density_bias;
     F.contract_radius = c.contract_radius; F.bg = c.bg_intensity;

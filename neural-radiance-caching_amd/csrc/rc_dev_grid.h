@@ -61,7 +61,12 @@ __device__ __forceinline__ float unit_box(float bbox, float x) { return (x - (-b
 // POW2: the caller guarantees power-of-two hash tables (mask != 0): no modulo path.
 // STRIDE: distance between consecutive entries in units of F floats (2 for the interleaved [density | appearance]
 // tables of the fused kernel, where `table` already points at this lane's half of an entry pair).
-template <int F, bool POW2 = false, int STRIDE = 1>
+// CELL (dense levels of the fused kernel): `table` is a cell table built by the host -- for every cell origin of the
+// zero-padded volume, (N + 3)^3 of them, the 8 corner entries in combine order, zeros for the padding already in
+// place -- so a lane reads its 8 corners from ONE contiguous block (32 bytes for F = 1: two 16-byte loads; with
+// STRIDE = 2 a 256-byte block of [density | appearance] pairs) instead of four scattered line pairs, and the clamp /
+// zero-mask arithmetic per corner disappears.
+template <int F, bool POW2 = false, int STRIDE = 1, bool CELL = false>
 __device__ __forceinline__ void grid_fetch(const float* __restrict__ table, int size, uint32_t mask, uint32_t entries,
                                            bool dense, float x01, float y01, float z01, Corners<F>& C) {
   const float N = (float)size;
@@ -79,6 +84,23 @@ __device__ __forceinline__ void grid_fetch(const float* __restrict__ table, int 
       const float fl = floorf(loc[a]);
       C.cw[a] = loc[a] - fl;
       base[a] = (int)fl;
+    }
+    if constexpr (CELL) {
+      // cell origin clamped to [-1, N + 1]: beyond that both corners of an axis are padding anyway
+      const int M = size + 3;
+      const int q0 = min(max(base[0], -1), size + 1) + 1, q1 = min(max(base[1], -1), size + 1) + 1,
+                q2 = min(max(base[2], -1), size + 1) + 1;
+      const uint32_t cell = ((uint32_t)q2 * (uint32_t)M + (uint32_t)q1) * (uint32_t)M + (uint32_t)q0;
+      if constexpr (F == 1 && STRIDE == 1) {
+        const float4* cp = reinterpret_cast<const float4*>(table) + (size_t)cell * 2;
+        const float4 lo = cp[0], hi = cp[1];
+        C.val[0].v[0] = lo.x; C.val[1].v[0] = lo.y; C.val[2].v[0] = lo.z; C.val[3].v[0] = lo.w;
+        C.val[4].v[0] = hi.x; C.val[5].v[0] = hi.y; C.val[6].v[0] = hi.z; C.val[7].v[0] = hi.w;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) C.val[c] = load_entry<F>(table, (cell * 8u + (uint32_t)c) * STRIDE);
+      }
+      return;
     }
     // clamp to the padded volume [0, N+1]; the pad (0 and N+1) holds zeros (grid_utils.py:384-390, 435-438);
     // data[loc2, loc1, loc0] = grid[x, y, z]: idx = ((k2-1) N + (k1-1)) N + (k0-1)

@@ -88,6 +88,7 @@ struct RcFusedArgs {
   const float* jitter[3];
   RcGridDev grid[4];
   const float* pair_table[RC_MAX_GRID_LEVELS];
+  const float* cell_table[2][RC_MAX_GRID_LEVELS];
   const float* wstream; const float* ide_coef;
   USpec us[3];
   float anneal, padding, density_bias, contract_radius, bg;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
       Corners<1> C[6];          // all 48 corner loads in flight before the first combine
       RC_FSTAMP(12);
 #pragma unroll
-      for (int l = 0; l < 6; ++l) { const RcGridLevel& L = a.grid[0].lvl[l]; grid_fetch<1, true>(L.table, L.size, L.mask, 0u, L.dense != 0, ux, uy, uz, C[l]); }
+      for (int l = 0; l < 6; ++l) { const RcGridLevel& L = a.grid[0].lvl[l]; grid_fetch<1, true, 1, true>(L.dense ? a.cell_table[0][l] : L.table, L.size, L.mask, 0u, L.dense != 0, ux, uy, uz, C[l]); }
       RC_FSTAMP_NOWAIT(13);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
       const float ux = unit_box(a.grid[1].bbox, cx), uy = unit_box(a.grid[1].bbox, cy), uz = unit_box(a.grid[1].bbox, cz);
       Corners<1> C[7];          // all 56 corner loads in flight before the first combine
 #pragma unroll
-      for (int l = 0; l < 7; ++l) { const RcGridLevel& L = a.grid[1].lvl[l]; grid_fetch<1, true>(L.table, L.size, L.mask, 0u, L.dense != 0, ux, uy, uz, C[l]); }
+      for (int l = 0; l < 7; ++l) { const RcGridLevel& L = a.grid[1].lvl[l]; grid_fetch<1, true, 1, true>(L.dense ? a.cell_table[1][l] : L.table, L.size, L.mask, 0u, L.dense != 0, ux, uy, uz, C[l]); }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int l = 0; l < 7; ++l) {
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
         // a copy of the two tables interleaved entry by entry ([density 16 B | appearance 16 B]), so the two half-waves
         // of a point read the two halves of ONE 32-byte pair -- half the cache-line requests and sector traffic
         const RcGridLevel& L = a.grid[2].lvl[l];
-        grid_fetch<4, true, 2>(a.pair_table[l] + 4 * h, L.size, L.mask, 0u, L.dense != 0, ux, uy, uz, C[q]);
+        grid_fetch<4, true, 2, true>(a.pair_table[l] + 4 * h, L.size, L.mask, 0u, L.dense != 0, ux, uy, uz, C[q]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -455,6 +456,29 @@ static unsigned long long* g_fused_stamps = nullptr;
 extern "C" void* rc_debug_fused_stamps() { return g_fused_stamps; }
 #endif
 
+__global__ void k_build_cells(const float* __restrict__ src, int N, int F, float* __restrict__ dst, int dst_stride, int dst_off) {
+  const int M = N + 3;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)M * M * M * 8;
+  if (i >= total) return;
+  const int c = (int)(i & 7);
+  int64_t cell = i >> 3;
+  const int q0 = (int)(cell % M); cell /= M;
+  const int q1 = (int)(cell % M);
+  const int q2 = (int)(cell / M);
+  const int b0 = (c >> 2) & 1, b1 = (c >> 1) & 1, b2 = c & 1;
+  // cell origin q - 1 in padded coordinates; corners clamp to the padded volume [0, N + 1] (grid_utils.py:384-390)
+  const int k0 = min(max(q0 - 1 + b0, 0), N + 1), k1 = min(max(q1 - 1 + b1, 0), N + 1), k2 = min(max(q2 - 1 + b2, 0), N + 1);
+  const bool inside = (k0 >= 1) & (k0 <= N) & (k1 >= 1) & (k1 <= N) & (k2 >= 1) & (k2 <= N);
+  const int64_t e = ((int64_t)(k2 - 1) * N + (k1 - 1)) * N + (k0 - 1);
+  for (int f = 0; f < F; ++f) dst[i * dst_stride + dst_off + f] = inside ? src[e * F + f] : 0.0f;
+}
+
+void rc_launch_build_cells(const float* src, int N, int F, float* dst, int dst_stride, int dst_off, hipStream_t stream) {
+  const int64_t total = (int64_t)(N + 3) * (N + 3) * (N + 3) * 8;
+  hipLaunchKernelGGL(k_build_cells, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, N, F, dst, dst_stride, dst_off);
+}
+
 int rc_fused_stream_offsets(int* l0, int* l1, int* l2, int* sh) {
   *l0 = F_L0; *l1 = F_L1; *l2 = F_L2; *sh = F_SH;
   return NF;
@@ -473,7 +497,10 @@ void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream) {
   a.far = L.rays.far; a.lights = L.rays.lights; a.n = L.n;
   for (int l = 0; l < 3; ++l) { a.jitter[l] = L.jitter[l]; a.us[l] = make_uspec(L.num_samples[l], L.jitter[l] != nullptr); }
   for (int g = 0; g < 4; ++g) a.grid[g] = *L.grid[g];
-  for (int l = 0; l < RC_MAX_GRID_LEVELS; ++l) a.pair_table[l] = L.pair_table[l];
+  for (int l = 0; l < RC_MAX_GRID_LEVELS; ++l) {
+    a.pair_table[l] = L.pair_table[l];
+    a.cell_table[0][l] = L.cell_table[0][l]; a.cell_table[1][l] = L.cell_table[1][l];
+  }
   a.wstream = L.wstream; a.ide_coef = L.ide_coef;
   a.anneal = L.anneal; a.padding = L.padding; a.density_bias = L.density_bias; a.contract_radius = L.contract_radius; a.bg = L.bg;
   for (int i = 0; i < 3; ++i) a.pct[i] = L.pct[i];

@@ -224,6 +224,8 @@ struct RcFusedLaunch {
   const float* jitter[3]; int32_t num_samples[3];
   const RcGridDev* grid[4];            // proposal 0, 1, 2 + appearance
   const float* pair_table[RC_MAX_GRID_LEVELS];   // level-2 density and appearance tables interleaved entry by entry
+                                                 // (dense levels: cell tables of interleaved pairs)
+  const float* cell_table[2][RC_MAX_GRID_LEVELS]; // dense levels of proposal grids 0 / 1 as cell tables (else NULL)
   const float* wstream;                // [density MLP 0 | 1 | 2 (+ backward) | shader], see rc_fused_stream_offsets
   const float* ide_coef;
   float anneal, padding, density_bias, contract_radius, bg; float pct[3];
@@ -232,6 +234,9 @@ struct RcFusedLaunch {
 };
 int rc_fused_stream_offsets(int* l0, int* l1, int* l2, int* sh);   // returns the total fragment count
 void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream);
+// dst[cell][corner][dst_stride floats, written F at dst_off]: the 8 corners of every cell of the zero-padded dense
+// level `src` [N^3][F] (cells (N + 3)^3, corner order b0 b1 b2 as in grid_combine)
+void rc_launch_build_cells(const float* src, int N, int F, float* dst, int dst_stride, int dst_off, hipStream_t stream);
 
 
 // ---------------------------------------------------------------------------------------------
