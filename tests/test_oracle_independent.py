@@ -115,3 +115,59 @@ def test_sample_intervals_equals_numpy_inverse_cdf():
         # the oracle keeps jnp.linspace's float32 end points (pad, 1 - pad - eps are rounded to float32 as in the
         # reference) and its start (1 - s) + stop s form: within one float32 ulp of numpy's double linspace
         assert np.abs(got[r] - want).max() <= 2e-7
+
+
+# ---------------------------------------------------------------------------------------------
+# material stage: samplers and densities
+# ---------------------------------------------------------------------------------------------
+def test_vmf_density_equals_scipy_and_sampler_inverts_its_cdf():
+    from scipy import stats
+    from oracle import material_ref as mr
+    rng = np.random.default_rng(5)
+    mu = rng.normal(size=3); mu /= np.linalg.norm(mu)
+    x = rng.normal(size=(200, 3)); x /= np.linalg.norm(x, axis=-1, keepdims=True)
+    for kappa in (0.5, 5.0, 50.0):
+        got = mr.eval_vmf(torch.from_numpy(x), torch.from_numpy(mu)[None], torch.tensor(kappa, dtype=F64)).numpy()
+        ref = stats.vonmises_fisher(mu, kappa).pdf(x)
+        assert np.abs(got / ref - 1).max() <= 1e-10, kappa
+    # sample_vmf: w = cos(angle to the mean) = 1 + log(u + (1 - u) exp(-2 kappa)) / kappa is the inverse of the
+    # vMF marginal CDF F(w) = (exp(kappa w) - exp(-kappa)) / (exp(kappa) - exp(-kappa))
+    n = 64
+    vm = {"vmf_means": torch.from_numpy(np.tile(mu, (n, 4, 1))), "vmf_kappas": torch.full((n, 4, 1), 7.0, dtype=F64),
+          "vmf_logits": torch.zeros(n, 4, 1, dtype=F64)}
+    u = rng.uniform(size=(n, 3))
+    dirs, pdf = mr.light_sample(vm, torch.zeros(n, dtype=torch.int64), torch.from_numpy(rng.normal(size=(n, 3, 2))), torch.from_numpy(u))
+    w = (dirs.numpy() * mu).sum(-1)
+    cdf = (np.exp(7.0 * w) - np.exp(-7.0)) / (np.exp(7.0) - np.exp(-7.0))
+    assert np.abs(cdf - u).max() <= 1e-9 and np.abs(np.linalg.norm(dirs.numpy(), axis=-1) - 1).max() <= 1e-12
+    assert np.abs(pdf.numpy() / stats.vonmises_fisher(mu, 7.0).pdf(dirs.numpy().reshape(-1, 3)).reshape(n, 3) - 1).max() <= 1e-9
+
+
+def test_ggx_normal_distribution_is_normalised_and_sampled_by_inverse_cdf():
+    from scipy import integrate
+    from oracle import material_ref as mr
+    for a in (0.05, 0.3, 0.9):
+        # D(h) cos(theta_h) integrates to 1 over the hemisphere
+        f = lambda th: float(mr.ggx_d(torch.tensor(np.cos(th), dtype=F64), torch.tensor(a, dtype=F64))) * np.cos(th) * np.sin(th) * 2 * np.pi
+        val, _ = integrate.quad(f, 0.0, np.pi / 2, limit=200)
+        assert abs(val - 1.0) <= 1e-6, a
+    # the sampler draws the microfacet normal with tan^2(theta) = a^2 u / (1 - u), i.e. u = CDF(theta)
+    rng = np.random.default_rng(6)
+    u1 = torch.from_numpy(rng.uniform(0.01, 0.99, size=(50, 1))); u2 = torch.from_numpy(rng.uniform(size=(50, 1)))
+    wo = torch.tensor([[0.0, 0.0, 1.0]], dtype=F64).expand(50, 1, 3)          # view along the normal: reflect(wo, n) = 2 n_z n - wo
+    alpha = torch.full((50, 1), 0.4, dtype=F64)
+    d, pdf = mr.microfacet_sample(u1, u2, wo, alpha)
+    n = (d + wo); n = n / torch.linalg.norm(n, dim=-1, keepdim=True)            # half vector = sampled microfacet normal
+    tan2 = (1 - n[..., 2] ** 2) / n[..., 2] ** 2
+    assert np.abs((tan2 / (0.4 ** 2 + tan2)).numpy() - u1.numpy()).max() <= 1e-9
+    assert np.abs(pdf.numpy() / mr.microfacet_pdf(wo, d, alpha).numpy() - 1).max() <= 1e-9
+
+
+def test_cosine_sampler_density_by_quadrature():
+    from oracle import material_ref as mr
+    rng = np.random.default_rng(7)
+    u1, u2 = torch.from_numpy(rng.uniform(size=(4000,))), torch.from_numpy(rng.uniform(size=(4000,)))
+    d, pdf = mr.cosine_sample(u1, u2)
+    d = d.numpy()
+    assert np.abs(np.linalg.norm(d, axis=-1) - 1).max() <= 1e-9 and np.abs(pdf.numpy() - d[:, 2] / np.pi).max() <= 1e-12
+    assert abs(d[:, 2].mean() - 2.0 / 3.0) <= 0.02                              # E[cos] under p = cos / pi
