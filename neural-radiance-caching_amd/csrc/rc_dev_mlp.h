@@ -260,14 +260,14 @@ __host__ __device__ constexpr int ide_m(int i) { return i < 2 ? i : (i < 5 ? i -
 
 
 // activation slice of the shader (steps): [0,48) feature (hidden 32 | appearance 16) | [48,84) IDE | 84 bias(1|0) |
-// 85 (dot|1).  The 128-wide shader bottleneck (Dense(96 -> 128) WITHOUT activation, nerf.py:394-396) only feeds
+// (the (n.v | 1) step of the integrated BRDF reuses step 48 once the IDE is dead).  The 128-wide shader bottleneck
+// (Dense(96 -> 128) WITHOUT activation, nerf.py:394-396) only feeds
 // linear layers -- SLF layer_0, the input part of SLF layer_bottleneck, integrated_brdf_layers_0 -- so the host
 // folds it into those (W' = W_b W[:128], b' = b + b_b W[:128], products in fp64): the layer itself and 16 k-steps of
 // each consumer disappear (1767 instead of 2123 MFMAs per tile), results equal up to fp32 rounding of the folded weights.
 constexpr int kShActSteps = 102;
 constexpr int kStepIde = 48;
 constexpr int kStepBias = 84;
-constexpr int kStepDot = 85;
 
 // fragment offsets of the shader's layers inside its weight stream (host: rc_api.hip, same order)
 struct ShaderFrags {
@@ -312,12 +312,13 @@ __device__ __forceinline__ ShadeOut shader_tile(const WStream& ws, float* act, i
   }
   RC_TSTAMP(1);
   // ---- normals, n.(-v), reflection direction, IDE
+  float dot_nv;
   {
     const float dotp = nx * (-vx) + ny * (-vy) + nz * (-vz);        // nerf.py:474
     // reflect(-v, n) = 2 (n . -v) n - (-v)  (ref_utils.py:25-42)
     const float rx = 2.0f * dotp * nx - (-vx), ry = 2.0f * dotp * ny - (-vy), rz = 2.0f * dotp * nz - (-vz);
     act[kStepBias * 64] = h == 0 ? 1.0f : 0.0f;
-    act[kStepDot * 64] = h == 0 ? dotp : 1.0f;
+    dot_nv = dotp;
     // IDE (ref_utils.py:155-190): low half-wave keeps real parts, high half-wave imaginary parts.
     float zp[RC_IDE_ZPOW];
     zp[0] = 1.0f;
@@ -361,9 +362,10 @@ __device__ __forceinline__ ShadeOut shader_tile(const WStream& ws, float* act, i
   {
     f32x16 ib[2];
     ib[0] = zero16(); ib[1] = zero16();
-    mlp_layer<2, 48, F0 + ShaderFrags::F_I0, NF>(ws, act, ib);
-    mlp_layer<2, 1, F0 + ShaderFrags::F_I0 + 96, NF>(ws, act + kStepDot * 64, ib);   // (n.v | bias) step
-    // IDE is dead now: steps [48, 81) are scratch for the IBRDF tail
+    // IDE is dead after s0': its first step becomes the (n.v | bias) step right behind the 48 feature steps
+    act[48 * 64] = h == 0 ? dot_nv : 1.0f;
+    mlp_layer<2, 49, F0 + ShaderFrags::F_I0, NF>(ws, act, ib);
+    // steps [48, 81) are scratch for the IBRDF tail
     park<2, true>(ib, act, 48);
     act[(48 + 32) * 64] = h == 0 ? 1.0f : 0.0f;
     ib[0] = zero16(); ib[1] = zero16();
