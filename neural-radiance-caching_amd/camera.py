@@ -39,12 +39,20 @@ def cast_ray_batch(rc, camera: Camera, pix_x_int=None, pix_y_int=None, rect=None
 
 
 def render_camera(model, camera: Camera, height: int, width: int, passes=("cache",), rows_per_chunk: Optional[int] = None,
-                  keys=("rgb", "acc", "distance_median"), streams: int = 1, to_host: bool = True):
+                  keys=("rgb", "acc", "distance_median"), streams: int = 1, to_host: bool = True, rng=None):
     """Image of one camera without a host-side ray batch: rows of pixels are cast on the device and rendered
     chunk by chunk; returns {key: [H, W, ...]} (numpy, or cuda tensors with to_host=False).  Default chunk: whole rows
     covering >= 16 384 rays (one fused launch each; an 800 x 800 image takes 78-83 ms on one MI355X, 7.7-8.2 M rays/s).
-    Chunks are independent: with streams > 1 they alternate between HIP streams (pays off for small chunks only)."""
+    Chunks are independent: with streams > 1 they alternate between HIP streams (pays off for small chunks only).
+    rng: None (deterministic sampling branch) or a uint32[2] key (prng.PRNGKey): the per-ray jitter is then generated
+    in HBM (rc_prng_fill) from the keys the reference's render_image -> render_eval_fn -> model chain would derive
+    for each chunk (models.py:2445, train_utils.py:3794-3818; prng.py), nothing is uploaded."""
     import torch
+
+    from . import prng
+    if rng is not None:
+        rng = prng.as_key(rng)
+    levels = [lvl[2] for lvl in model.config.sampling_strategy]
 
     chunk = model.config.render_chunk_size
     rows = rows_per_chunk or max(1, max(chunk, 16384) // width)
@@ -60,7 +68,18 @@ def render_camera(model, camera: Camera, height: int, width: int, passes=("cache
             st.wait_event(start)
         with torch.cuda.stream(st):
             rays = cast_ray_batch(model.rc, camera, rect=(0, y0, width, hgt))
-            r = model.apply(None, None, rays, passes=passes)["render"]
+            randoms = None
+            if rng is not None:
+                apply_key, rng = prng.random_split(rng)
+                rng, _ = prng.random_split(rng)                 # the key render_eval_fn hands back for the next chunk
+                s_key = prng.cache_keys(prng.model_cache_rng(apply_key))["sampler"]
+                jit = []
+                for _ in levels:                                # sampling.py:341 / :408
+                    k, s_key = prng.random_split(s_key)
+                    jit.append(model.rc.prng_fill(k, (hgt * width,), "uniform"))
+                    _, s_key = prng.random_split(s_key)
+                randoms = {"jitter": jit}
+            r = model.apply(None, randoms, rays, passes=passes)["render"]
             for k in keys:
                 v = r[k]
                 if k not in out:

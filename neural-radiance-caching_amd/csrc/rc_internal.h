@@ -302,6 +302,17 @@ struct RcCastArgs {
 };
 void rc_launch_cast_rays(const RcCastArgs& a, hipStream_t stream);
 
+// Random fill (rc_prng.hip)
+enum { RC_PRNG_BITS = 0, RC_PRNG_UNIFORM = 1, RC_PRNG_NORMAL = 2, RC_PRNG_GUMBEL = 3 };
+struct RcPrngArgs {
+  uint32_t key0, key1;
+  int mode;
+  float lo, hi;
+  int64_t n;
+  uint32_t* out;
+};
+void rc_launch_prng_fill(const RcPrngArgs& a, hipStream_t stream);
+
 
 // Kernel attributes (dynamic-LDS limit) are per device: true the first time the calling thread's current device
 // shows up for this `mask` (one mask per kernel), so a process driving several GPUs sets them on each.

@@ -15,8 +15,11 @@ leading device axis of the reference's pmap outputs is kept with size 1 so calle
 `render_image_distributed`, with one all-gather of the consumed keys per image (RCCL over xGMI
 via torch.distributed's "nccl" backend; "gloo" on CPU for the tests).
 
-Randomness: jax.random (threefry) is not reproduced.  `rng` may be
+Randomness: `rng` may be
   * None                         -> the reference's rng=None deterministic branch,
+  * a uint32[2] key (prng.PRNGKey)-> the tensors jax.random would draw from that key at the reference's
+                                    random_split sites (prng.py; threefry2x32 pinned by published known answers,
+                                    the call order restated from the source and not checkable without jax),
   * a numpy Generator / int seed -> per-level ray jitter (and Gumbel noise) drawn here,
   * a dict {"jitter": [...], "gumbel": ..., "resample_inds": ...} of explicit tensors.
 """
@@ -27,7 +30,7 @@ from typing import Any, Dict, Optional, Tuple
 
 import numpy as np
 
-from . import rc_ext
+from . import prng, rc_ext
 from .config import RenderConfig
 from .rays import Rays
 
@@ -63,6 +66,8 @@ def _draw_randoms(rng, n: int, cfg: RenderConfig, need_gumbel: bool):
         return None, None
     if isinstance(rng, dict):
         return rng, None
+    if prng.is_key(rng):
+        return prng.cache_pass_randoms(rng, n, [lvl[2] for lvl in cfg.sampling_strategy], need_gumbel), None
     if isinstance(rng, (int, np.integer)):
         rng = np.random.Generator(np.random.PCG64(int(rng)))
     out = {"jitter": [rng.uniform(size=(n,)).astype(np.float32) for _ in range(cfg.num_levels)]}
@@ -170,9 +175,13 @@ class Model:
         include/rc_abi.h; oracle-compatible generator: oracle.material_ref.draw_randoms)."""
         import torch
 
-        if not isinstance(rng, dict) or "vmf_noise" not in rng:
+        if not isinstance(rng, dict):
             raise ValueError("the material stage needs explicit random tensors: pass rng as the dict described "
-                             "by rc_material_randoms (jax.random is not reproduced)")
+                             "by rc_material_randoms (only the cache pass derives its tensors from a key)")
+        if "vmf_noise" not in rng:
+            # the reference's constant: normal(random_split(PRNGKey(1))[0], [R, 1, 128, 3]) (light_sampler.py:135-144)
+            n_rays = int(np.prod(np.shape(rays.origins if isinstance(rays, Rays) else rays["origins"])[:-1]))
+            rng = dict(rng, vmf_noise=prng.light_vmf_noise((n_rays, 1, self.config.num_vmf, 3))[:, 0])
         if variables is not None and id(variables) != self._variables_id:
             self.load_variables(variables)
         fields = rays.hot_fields() if isinstance(rays, Rays) else dict(rays)
@@ -245,9 +254,18 @@ def create_render_fn(model: Model, variables=None):
 
     def render_fn(rng, rays: Rays, passes, resample=None):
         flat = rays.tree_map(lambda x: x.reshape((-1,) + tuple(x.shape[2:])))
-        out = model.apply(variables, rng, flat, train=False, passes=passes, resample=resample, compute_extras=True)
+        dev_keys = isinstance(rng, np.ndarray) and rng.dtype == np.uint32 and rng.shape == (1, 2)
+        key = rng[0] if dev_keys else rng
+        if prng.is_key(key):
+            # render_eval_fn: one split for model.apply, one for the rng handed back (train_utils.py:3794, 3817-3818)
+            apply_key, key = prng.random_split(key)
+            next_key, _ = prng.random_split(key)
+            next_rng = next_key[None] if dev_keys else next_key
+        else:
+            apply_key, next_rng = rng, rng
+        out = model.apply(variables, apply_key, flat, train=False, passes=passes, resample=resample, compute_extras=True)
         render = {k: v[None, None] for k, v in out["render"].items()}
-        return render, rng
+        return render, next_rng
 
     return render_fn
 

@@ -141,6 +141,7 @@ EXPORTS = (
     "rc_create", "rc_destroy", "rc_last_error", "rc_abi_version", "rc_load_weights", "rc_render_rays",
     "rc_hashgrid_lookup", "rc_sample_intervals", "rc_workspace_ptr", "rc_set_profiling", "rc_stage_count",
     "rc_stage_name", "rc_stage_times_ms", "rc_set_graph_mode", "rc_set_fused", "rc_render_material", "rc_set_transient", "rc_render_transient", "rc_cast_rays",
+    "rc_prng_fill",
 )
 
 _LIB = None
@@ -198,6 +199,8 @@ def load_library():
     lib.rc_cast_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_int32, C.c_void_p, C.c_void_p]
     lib.rc_cast_rays.restype = C.c_int
+    lib.rc_prng_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.rc_prng_fill.restype = C.c_int
     lib.rc_stage_count.restype = C.c_int
     lib.rc_stage_name.argtypes = [C.c_int32]
     lib.rc_stage_name.restype = C.c_char_p
@@ -395,6 +398,22 @@ class RadianceCache:
             if t.shape[0] != n:
                 raise ValueError(f"ray field {k} has {t.shape[0]} rows, expected {n}")
         return r, held, n
+
+    def prng_fill(self, key, shape, mode: str = "uniform", minval: float = 0.0, maxval: float = 1.0):
+        """rc_prng_fill: the tensor jax.random.{bits,uniform,normal,gumbel}(key, shape) of the reference's pinned jax
+        holds, generated in HBM.  key: uint32[2] (prng.PRNGKey / prng.split)."""
+        from . import prng
+        torch = self._torch
+        modes = {"bits": prng.MODE_BITS, "uniform": prng.MODE_UNIFORM, "normal": prng.MODE_NORMAL, "gumbel": prng.MODE_GUMBEL}
+        if mode not in modes:
+            raise ValueError(f"unknown mode {mode!r}")
+        k = (C.c_uint32 * 2)(*[int(v) for v in prng.as_key(key)])
+        shape = tuple(int(v) for v in shape)
+        n = int(np.prod(shape)) if shape else 1
+        out = torch.empty(shape, dtype=torch.int32 if mode == "bits" else torch.float32, device=f"cuda:{self.device}")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.rc_prng_fill(self._h, k, modes[mode], float(minval), float(maxval), n, out.data_ptr(), stream))
+        return out
 
     def cast_rays(self, camera, pix_x_int=None, pix_y_int=None, rect=None):
         """rc_cast_rays: pinhole rays of `camera` (pixtocam [3,3], camtoworld [3,4], light, near, far) for an explicit

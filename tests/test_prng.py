@@ -1,0 +1,189 @@
+"""jax.random-compatible PRNG: host module against published known answers, the
+reference's random_split order as restated in prng.py, and the device fill against the host module."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from nrc_amd import prng
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def kat():
+    with open(os.path.join(HERE, "golden", "prng_kat.json")) as f:
+        return json.load(f)
+
+
+def test_threefry_known_answers(kat):
+    for v in kat["threefry2x32"]:
+        key = [int(x, 16) for x in v["key"]]
+        ctr = [int(x, 16) for x in v["counter"]]
+        a, b = prng.threefry2x32(key, [ctr[0]], [ctr[1]])
+        assert [int(a[0]), int(b[0])] == [int(x, 16) for x in v["out"]]
+
+
+def test_split_and_uniform_match_published_jax_outputs(kat):
+    d = kat["jax_docs"]
+    assert prng.PRNGKey(0).tolist() == [0, 0] and prng.PRNGKey(2 ** 32 + 5).tolist() == [1, 5]
+    assert prng.split(prng.PRNGKey(0)).tolist() == d["split_key0"]
+    assert prng.split(prng.PRNGKey(42)).tolist() == d["split_key42"]
+    assert np.float32(prng.uniform(prng.PRNGKey(0))) == np.float32(d["uniform_key0_scalar"])
+
+
+def test_normal_matches_published_jax_outputs(kat):
+    d = kat["jax_docs"]
+    # printed with 8 significant digits: equal after the same rounding
+    def same(a, b):
+        return np.allclose(np.asarray(a, np.float32), np.asarray(b, np.float32), rtol=3e-7, atol=0)
+    assert same(prng.normal(prng.PRNGKey(0)), d["normal_key0_scalar"])
+    assert same(prng.normal(prng.PRNGKey(0), (1,))[0], d["normal_key0_scalar"])
+    assert same(prng.normal(prng.PRNGKey(42)), d["normal_key42_scalar"])
+    assert same(prng.normal(prng.split(prng.PRNGKey(42))[1]), d["normal_key42_subkey_scalar"])
+    assert same(prng.normal(prng.PRNGKey(0), (10,)), d["normal_key0_10"])
+
+
+def test_counter_layout_properties():
+    key = prng.PRNGKey(20200823)
+    # odd sizes: padded with a zero counter, last word dropped -> a prefix relation does NOT hold, shapes only reshape
+    a = prng.random_bits(key, (7,))
+    b = prng.random_bits(key, (8,))
+    assert a.shape == (7,) and not np.array_equal(a, b[:7])
+    assert np.array_equal(prng.random_bits(key, (4, 6)).ravel(), prng.random_bits(key, (24,)))
+    # block i = (counter i, counter i + half)
+    x0, x1 = prng.threefry2x32(key, np.arange(4, dtype=np.uint32), np.arange(4, 8, dtype=np.uint32))
+    assert np.array_equal(b, np.concatenate([x0, x1]))
+    # fold_in is one block with counter [0, data]
+    f0, f1 = prng.threefry2x32(key, [0], [9])
+    assert prng.fold_in(key, 9).tolist() == [int(f0[0]), int(f1[0])]
+    u = prng.uniform(key, (1000,), 2.0, 6.0)
+    assert u.dtype == np.float32 and u.min() >= 2.0 and u.max() < 6.0
+    g = prng.gumbel(key, (1000,))
+    assert np.isfinite(g).all()
+    n = prng.normal(key, (20000,))
+    assert abs(float(n.mean())) < 0.03 and abs(float(n.std()) - 1.0) < 0.03
+
+
+def test_categorical_shape_and_distribution():
+    key = prng.PRNGKey(3)
+    logits = np.log(np.array([0.1, 0.2, 0.7], np.float32))
+    # models.py:240-247 shape: logits [R, S, 1], axis -2, shape [R, n]
+    R, n = 4000, 1
+    inds = prng.categorical(key, np.broadcast_to(logits[None, :, None], (R, 3, 1)), axis=-2, shape=(R, n))
+    assert inds.shape == (R, n)
+    freq = np.bincount(inds.ravel(), minlength=3) / R
+    assert np.allclose(freq, [0.1, 0.2, 0.7], atol=0.03)
+    # equals argmax of the gumbel tensor drawn with shape [R, S, n]
+    g = prng.gumbel(key, (R, 3, n))
+    assert np.array_equal(inds, np.argmax(g + logits[None, :, None], axis=1))
+
+
+def test_reference_call_order_of_the_cache_pass():
+    """cache_pass_randoms == the random_split sequence read from models.py:1156/1176/1375/710-748 and
+    sampling.py:341/408, spelled out with split() here."""
+    rng = prng.PRNGKey(20200823)
+    R, S = 16, (64, 64, 32)
+    rnd = prng.cache_pass_randoms(rng, R, S, resample=True)
+    r = prng.split(rng)[1]                      # bypass key consumed
+    k_pass = prng.split(r)[0]                   # cache pass
+    k_cache = prng.split(k_pass)[0]             # _handle_cache_pass
+    k_sampler, r = prng.split(k_cache)
+    k_resample, r = prng.split(r)
+    s = k_sampler
+    for lvl in range(3):
+        k, s = prng.split(s)
+        assert np.array_equal(rnd["jitter"][lvl], prng.uniform(k, (R, 1)))
+        assert rnd["jitter"][lvl].min() >= 0 and rnd["jitter"][lvl].max() < 1
+        s = prng.split(s)[1]
+    k = prng.split(k_resample)[0]
+    assert np.array_equal(rnd["gumbel"], prng.gumbel(k, (R, 32, 1))[..., 0])
+    # the jitter jax would add is unit * max_jitter in float32
+    mj = np.float32(prng.max_jitter(64))
+    assert np.array_equal(prng.uniform(prng.split(k_sampler)[0], (R, 1), 0.0, prng.max_jitter(64)),
+                          rnd["jitter"][0] * mj)
+
+
+def test_light_vmf_noise_is_constant_per_shape():
+    a = prng.light_vmf_noise((5, 1, 128, 3))
+    b = prng.light_vmf_noise((5, 1, 128, 3))
+    assert a.shape == (5, 1, 128, 3) and np.array_equal(a, b)
+    assert np.array_equal(a, prng.normal(prng.split(prng.PRNGKey(1))[0], (5, 1, 128, 3)))
+
+
+def test_model_accepts_a_key_without_gpu():
+    from nrc_amd import model as m
+    from nrc_amd.config import hotdog_config
+    cfg = hotdog_config()
+    rnd, _ = m._draw_randoms(prng.PRNGKey(7), 8, cfg, True)
+    assert len(rnd["jitter"]) == 3 and rnd["gumbel"].shape == (8, 32)
+
+
+@pytest.mark.gpu
+def test_device_fill_matches_host_bitwise():
+    import torch
+    from nrc_amd import rc_ext
+    from nrc_amd.config import hotdog_config
+    rc = rc_ext.RadianceCache(hotdog_config())
+    key = prng.split(prng.PRNGKey(20200823))[1]
+    for shape in [(1,), (2,), (7,), (1024, 1), (1023, 3), (4096, 32), (1 << 21,)]:
+        bits = rc.prng_fill(key, shape, "bits").cpu().numpy().view(np.uint32)
+        assert np.array_equal(bits, prng.random_bits(key, shape)), shape
+        u = rc.prng_fill(key, shape, "uniform").cpu().numpy()
+        assert np.array_equal(u, prng.uniform(key, shape)), shape
+        u = rc.prng_fill(key, shape, "uniform", 2.0, 6.0).cpu().numpy()
+        assert np.array_equal(u, prng.uniform(key, shape, 2.0, 6.0)), shape
+    # normal / gumbel: libm differences of an ulp or two in log / log1p / sqrt
+    n = rc.prng_fill(key, (4096, 3), "normal").cpu().numpy()
+    np.testing.assert_allclose(n, prng.normal(key, (4096, 3)), rtol=2e-6, atol=2e-7)
+    g = rc.prng_fill(key, (4096, 32), "gumbel").cpu().numpy()
+    np.testing.assert_allclose(g, prng.gumbel(key, (4096, 32)), rtol=2e-6, atol=2e-6)
+    with pytest.raises(rc_ext.RcError):
+        rc.lib.rc_prng_fill.restype = __import__("ctypes").c_int
+        rc._check(rc.lib.rc_prng_fill(rc._h, None, 1, 0.0, 1.0, 4, 0, None))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_render_with_key_equals_render_with_its_tensors():
+    from common import weights_np
+    from nrc_amd import Rays, synthetic_rays
+    from nrc_amd.config import hotdog_config
+    from nrc_amd.model import Model
+    cfg = hotdog_config()
+    model = Model(cfg)
+    model.load_variables(weights_np())
+    rays = synthetic_rays(256, seed=5)
+    key = prng.PRNGKey(11)
+    a = model.apply(None, key, rays)["render"]
+    rnd = prng.cache_pass_randoms(key, 256, (64, 64, 32), resample=False)
+    b = model.apply(None, rnd, rays)["render"]
+    for k in ("rgb", "acc", "distance_median"):
+        assert np.array_equal(a[k].cpu().numpy(), b[k].cpu().numpy())
+    c = model.apply(None, prng.PRNGKey(12), rays)["render"]
+    assert not np.array_equal(a["rgb"].cpu().numpy(), c["rgb"].cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_render_camera_with_key_draws_the_chunk_keys_of_render_image():
+    """render_camera(rng=key) (jitter generated in HBM) == render_image(render_fn, key, host rays) chunk by chunk."""
+    from common import weights_np
+    from nrc_amd import Camera, get_pixtocam
+    from nrc_amd.camera import render_camera
+    from nrc_amd.config import hotdog_config
+    from nrc_amd.model import Model, create_render_fn, render_image
+    cfg = hotdog_config(render_chunk_size=512)
+    model = Model(cfg)
+    model.load_variables(weights_np())
+    H = W = 32
+    c2w = np.array([[1, 0, 0, 0.1], [0, 1, 0, 0.2], [0, 0, 1, 4.0]], np.float32)   # looks down -z at the scene ball
+    cam = Camera(pixtocam=get_pixtocam(40.0, W, H), camtoworld=c2w, light=None, near=2.0, far=6.0)
+    key = prng.PRNGKey(99)
+    a = render_camera(model, cam, H, W, rows_per_chunk=16, rng=key)
+    rays = model.rc.cast_rays(cam, rect=(0, 0, W, H)).tree_map(lambda t: t.cpu().numpy())
+    b, _ = render_image(create_render_fn(model), key, rays, cfg, ("cache",), verbose=False)
+    for k in ("rgb", "acc", "distance_median"):
+        assert np.array_equal(a[k].reshape(-1), b[k].reshape(-1)), k
+    d = render_camera(model, cam, H, W, rows_per_chunk=16, rng=None)
+    assert not np.array_equal(a["rgb"], d["rgb"])
