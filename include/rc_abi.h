@@ -360,6 +360,31 @@ typedef enum rc_prng_mode { RC_PRNG_MODE_BITS = 0, RC_PRNG_MODE_UNIFORM = 1, RC_
 int rc_prng_fill(rc_handle* h, const uint32_t key[2], int32_t mode, float minval, float maxval, int64_t n, void* out,
                  void* stream);
 
+/* ---- training backward of one proposal level's density field ----------------------
+ * Replaces, for the parameters of Cache/Sampler/MLP_<level>, the gradients jax.value_and_grad(loss_fn) yields in
+ * train_step (internal/train_utils.py:3128-3131) for the sub-graph HashEncoding.__call__
+ * (internal/grid_utils.py:808-905) -> DensityMLP.run_network (internal/geometry.py:155-168) ->
+ * convert_raw_density (internal/geometry.py:318-341), given the upstream gradients of its two outputs.
+ *   points     [n,3] world-space sample means (device)
+ *   d_density  [n]    d L / d density            d_feature  [n,64] d L / d feature (the hidden vector the shader
+ *                                                 reads) or NULL
+ *   grads      device buffer of rc_density_grad_size floats, layout rc_density_grad_layout (tensor names, offsets
+ *              and shapes of the reference's parameter tree); gradients are ACCUMULATED into it (zero it per step)
+ *   density_out [n] or NULL: the forward value, for the caller's loss
+ * Table gradients use hardware float atomics (order-dependent in the last bits); the MLP gradients are reduced in a
+ * fixed order.  Across ranks the caller averages `grads` (jax.lax.pmean, train_utils.py:3133-3135) with one
+ * all-reduce over RCCL (nrc_amd.train.allreduce_grads). */
+typedef struct rc_grad_segment {
+  char name[160];          /* e.g. params/Cache/Sampler/MLP_2/density_grid/hash_2048 */
+  int64_t offset, size;    /* in floats */
+  int32_t ndim;
+  int64_t shape[4];
+} rc_grad_segment;
+int64_t rc_density_grad_size(rc_handle* h, int32_t level);
+int rc_density_grad_layout(rc_handle* h, int32_t level, rc_grad_segment* segs, int32_t capacity, int32_t* count);
+int rc_density_backward(rc_handle* h, int32_t level, const float* points, int64_t n, const float* d_density,
+                        const float* d_feature, float* grads, float* density_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

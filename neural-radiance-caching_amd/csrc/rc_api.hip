@@ -76,6 +76,8 @@ struct rc_handle {
   GridState grids[6];
   std::map<std::string, HostLayer> layers;   // key: path without /kernel|/bias
   bool packed_dirty = true;
+  uint64_t layers_gen = 1;                   // bumped whenever a dense layer is (re)loaded
+  uint64_t train_gen[RC_MAX_LEVELS] = {};    // layers_gen the training stream of a level was packed at
   bool have_envmap = false;
   bool have_material = false;
   // packed MFMA fragments (device)
@@ -846,6 +848,7 @@ int rc_load_weights(rc_handle* h, const rc_tensor_desc* descs, int32_t n) {
     else memcpy(dst.data(), d.data, count * sizeof(float));
     (leaf == "kernel" ? L.have_kernel : L.have_bias) = true;
     h->packed_dirty = true;
+    ++h->layers_gen;
   }
   drop_graphs(h);   // table pointers / packed fragments are baked into captured kernel arguments
   return RC_OK;
@@ -1374,3 +1377,4 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
 }  // extern "C"
 
 #include "rc_transient_host.inc"
+#include "rc_train_host.inc"

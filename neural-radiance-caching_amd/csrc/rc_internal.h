@@ -302,6 +302,44 @@ struct RcCastArgs {
 };
 void rc_launch_cast_rays(const RcCastArgs& a, hipStream_t stream);
 
+// Training backward of one level's density field (rc_train.hip)
+struct RcDensityBwdArgs {
+  const float* feat;          // grid features, feature-major [K][ld] (k_hashgrid_fwd)
+  int64_t n; int64_t ld;
+  int32_t K;
+  const float* wstream;       // [d0 | d1 | out | W1^T | W0^T] fragments
+  const float* points;        // world-space [n,3]
+  float density_bias, contract_radius, bbox;
+  const float* d_density;     // [n] upstream
+  const float* d_feature;     // [n,64] upstream or nullptr
+  float* density;             // [n]
+  float* graw;                // [n] d L / d raw density
+  float* a1; float* a2; float* d2; float* d1;   // point-major [n,64]
+  float* fe;                  // point-major [n,32] staged grid features
+  float* dfeat;               // feature-major [K][ld] d L / d grid feature
+};
+void rc_launch_density_bwd(const RcDensityBwdArgs& a, hipStream_t stream);
+struct RcWgradArgs {
+  const float* a1; const float* d2; const float* fe; const float* d1; const float* a2; const float* graw;
+  int64_t n; int32_t K; int64_t steps_per_wave;
+  float* partial;             // [rc_wgrad_waves(n)][partial stride]
+};
+int rc_wgrad_waves(int64_t n);
+int rc_wgrad_partial_floats(int nwaves);
+// grads: [W0 K x 64 | b0 64 | W1 64 x 64 | b1 64 | Wout 64 | bout 1], accumulated into
+void rc_launch_wgrad(RcWgradArgs a, int K, float* grads, hipStream_t stream);
+struct RcGridScatterArgs {
+  RcGridDev grid;             // geometry of the forward tables
+  float* gtable[RC_MAX_GRID_LEVELS];   // gradient tables, same layout as the forward tables
+  const float* points;        // world-space [n,3]
+  int64_t n; int64_t ld;
+  const float* dfeat;         // feature-major [L*F][ld]
+  float contract_radius;
+  int32_t level0;             // first level of this launch (blockIdx.y = level - level0)
+  uint32_t lds_levels;        // bit l: level l is summed through LDS by k_grid_scatter_small
+};
+void rc_launch_grid_scatter(const RcGridScatterArgs& a, hipStream_t stream);
+
 // Random fill (rc_prng.hip)
 enum { RC_PRNG_BITS = 0, RC_PRNG_UNIFORM = 1, RC_PRNG_NORMAL = 2, RC_PRNG_GUMBEL = 3 };
 struct RcPrngArgs {

@@ -65,6 +65,11 @@ class rc_rays(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("origins", "directions", "viewdirs", "near", "far", "lights", "normals")]
 
 
+class rc_grad_segment(C.Structure):
+    _fields_ = [("name", C.c_char * 160), ("offset", C.c_int64), ("size", C.c_int64), ("ndim", C.c_int32),
+                ("shape", C.c_int64 * 4)]
+
+
 class rc_randoms(C.Structure):
     _fields_ = [("jitter", C.c_void_p * RC_MAX_LEVELS), ("gumbel", C.c_void_p), ("resample_inds", C.c_void_p)]
 
@@ -141,7 +146,7 @@ EXPORTS = (
     "rc_create", "rc_destroy", "rc_last_error", "rc_abi_version", "rc_load_weights", "rc_render_rays",
     "rc_hashgrid_lookup", "rc_sample_intervals", "rc_workspace_ptr", "rc_set_profiling", "rc_stage_count",
     "rc_stage_name", "rc_stage_times_ms", "rc_set_graph_mode", "rc_set_fused", "rc_render_material", "rc_set_transient", "rc_render_transient", "rc_cast_rays",
-    "rc_prng_fill",
+    "rc_prng_fill", "rc_density_grad_size", "rc_density_grad_layout", "rc_density_backward",
 )
 
 _LIB = None
@@ -201,6 +206,13 @@ def load_library():
     lib.rc_cast_rays.restype = C.c_int
     lib.rc_prng_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_int64, C.c_void_p, C.c_void_p]
     lib.rc_prng_fill.restype = C.c_int
+    lib.rc_density_grad_size.argtypes = [C.c_void_p, C.c_int32]
+    lib.rc_density_grad_size.restype = C.c_int64
+    lib.rc_density_grad_layout.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    lib.rc_density_grad_layout.restype = C.c_int
+    lib.rc_density_backward.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]
+    lib.rc_density_backward.restype = C.c_int
     lib.rc_stage_count.restype = C.c_int
     lib.rc_stage_name.argtypes = [C.c_int32]
     lib.rc_stage_name.restype = C.c_char_p
@@ -398,6 +410,48 @@ class RadianceCache:
             if t.shape[0] != n:
                 raise ValueError(f"ray field {k} has {t.shape[0]} rows, expected {n}")
         return r, held, n
+
+    def density_grad_layout(self, level: int):
+        """rc_density_grad_layout: [(tensor name, offset, shape)] of the gradient buffer of proposal level `level`
+        (the reference's parameter-tree names), and its total size in floats."""
+        cnt = C.c_int32()
+        self._check(self.lib.rc_density_grad_layout(self._h, level, None, 0, C.byref(cnt)))
+        segs = (rc_grad_segment * cnt.value)()
+        self._check(self.lib.rc_density_grad_layout(self._h, level, segs, cnt.value, C.byref(cnt)))
+        out = [(s.name.decode(), int(s.offset), tuple(int(v) for v in s.shape[: s.ndim])) for s in segs]
+        total = int(self.lib.rc_density_grad_size(self._h, level))
+        if total < 0:
+            self._check(total)
+        return out, total
+
+    def density_backward(self, level: int, points, d_density, d_feature=None, grads=None):
+        """rc_density_backward: gradients of L w.r.t. the hash-grid tables and the density MLP of proposal level `level`
+        given d L / d density [n] (and d L / d feature [n, 64]) at the world-space sample means `points` [n, 3].
+        Returns (grads, density): `grads` is the flat float32 cuda buffer of density_grad_layout(level), accumulated
+        into when passed in (zeroed and allocated otherwise)."""
+        torch = self._torch
+        pts = self._dev(points).reshape(-1, 3).contiguous()
+        n = pts.shape[0]
+        dd = self._dev(d_density).reshape(-1).contiguous()
+        if dd.shape[0] != n:
+            raise ValueError("d_density must have one value per point")
+        df = None
+        if d_feature is not None:
+            df = self._dev(d_feature).reshape(n, 64).contiguous()
+        total = int(self.lib.rc_density_grad_size(self._h, level))
+        if total < 0:
+            self._check(total)
+        if grads is None:
+            grads = torch.zeros(total, dtype=torch.float32, device=f"cuda:{self.device}")
+        elif grads.numel() != total or grads.dtype != torch.float32 or not grads.is_cuda or not grads.is_contiguous():
+            raise ValueError(f"grads must be a contiguous float32 cuda tensor of {total} elements")
+        dens = torch.empty(n, dtype=torch.float32, device=f"cuda:{self.device}")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.rc_density_backward(self._h, level, pts.data_ptr(), n, dd.data_ptr(),
+                                                 None if df is None else df.data_ptr(), grads.data_ptr(), dens.data_ptr(),
+                                                 stream))
+        self._keep = [pts, dd, df]
+        return grads, dens
 
     def prng_fill(self, key, shape, mode: str = "uniform", minval: float = 0.0, maxval: float = 1.0):
         """rc_prng_fill: the tensor jax.random.{bits,uniform,normal,gumbel}(key, shape) of the reference's pinned jax

@@ -90,3 +90,11 @@ def oracle_transient(n_rays, jitter_seed=None, seed=20200823, smooth=False, dtyp
     jit = None if jitter_seed is None else [torch.from_numpy(j).to(dtype) for j in jitters(n_rays, seed=jitter_seed)]
     sj = None if shadow_jitter_seed is None else [torch.from_numpy(j).to(dtype) for j in shadow_jitters(n_rays * 32, shadow_jitter_seed)]
     return transient_ref.transient_forward(to_torch(weights_transient_np(smooth, density_shift), dtype), cfg, rays_torch(rays, dtype), jit, sj)
+
+
+def make_rc(density_shift=0.0):
+    """GPU handle with the synthetic hotdog weights loaded (gpu tests only)."""
+    from nrc_amd import rc_ext
+    rc = rc_ext.RadianceCache(nrc_amd.hotdog_config(), 0)
+    rc.load_weights(weights_np(density_shift))
+    return rc
