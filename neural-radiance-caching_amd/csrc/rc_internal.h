@@ -322,7 +322,7 @@ void rc_launch_density_bwd(const RcDensityBwdArgs& a, hipStream_t stream);
 struct RcWgradArgs {
   const float* a1; const float* d2; const float* fe; const float* d1; const float* a2; const float* graw;
   int64_t n; int32_t K; int64_t steps_per_wave;
-  float* partial;             // [rc_wgrad_waves(n)][partial stride]
+  float* partial;             // [rc_wgrad_waves(n) / 4][partial stride]: one per workgroup
 };
 int rc_wgrad_waves(int64_t n);
 int rc_wgrad_partial_floats(int nwaves);

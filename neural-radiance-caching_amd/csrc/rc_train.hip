@@ -15,12 +15,13 @@
 //   k_wgrad         dW1 = a1^T d2, dW0 = feat^T d1 as MFMAs whose K axis is the POINT axis (both operands are rows of
 //                   point-major arrays: lane l reads point 2 s + (l >> 5), column l & 31 -- coalesced, no transpose),
 //                   db = column sums, dWout = a2^T g_raw on the VALU.  Persistent waves, accumulators in registers,
-//                   one partial result per wave.
+//                   the four waves of a workgroup added in wave order through LDS, one partial per workgroup.
 //   k_grad_reduce   sums the per-wave partials in a fixed order (deterministic weight gradients) into the caller's buffer.
-//   k_grid_scatter  transposed trilinear lookup: one thread per (point, level) recomputes the 8 corner indices /
-//                   weights exactly like the forward gather and adds w * dfeat with hardware float atomics
-//                   (global_atomic_add_f32; hash collisions and shared corners make atomics unavoidable, so table
-//                   gradients are order-dependent in the last bits).
+//   k_grid_scatter  transposed trilinear lookup: the lanes of a (point, level) recompute the 8 corner indices / weights
+//                   exactly like the forward gather and add w * dfeat with hardware float atomics
+//                   (global_atomic_add_f32, executed at the memory side; table gradients are order-dependent in the
+//                   last bits).  Lanes are laid out so that adds sharing a 64-byte row share a wave-instruction;
+//   k_grid_scatter_small  16^3 levels, where a whole batch hits a few hundred rows, are summed in LDS first.
 #include <hip/hip_runtime.h>
 
 #include "rc_dev_grid.h"
@@ -170,26 +171,34 @@ __global__ __launch_bounds__(256) void k_wgrad(RcWgradArgs a) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) { w0[i] = zero16(); w1[i][0] = zero16(); w1[i][1] = zero16(); }
   float b1[2] = {0.0f, 0.0f}, b0[2] = {0.0f, 0.0f};
-  for (int64_t s = s0; s < s1; ++s) {
-    const int64_t p = 2 * s + kh;
-    const bool ok = p < a.n;
-    float x1[2], e2[2], e1[2];
+  // groups of 4 k-steps: all 28 operand loads of a group are in flight before its 24 MFMAs
+  for (int64_t sg = s0; sg < s1; sg += 4) {
+    float x1[4][2], e2[4][2], e1[4][2], xf[4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      x1[t] = ok ? a.a1[p * 64 + 32 * t + c] : 0.0f;
-      e2[t] = ok ? a.d2[p * 64 + 32 * t + c] : 0.0f;
-      e1[t] = ok ? a.d1[p * 64 + 32 * t + c] : 0.0f;
+    for (int u = 0; u < 4; ++u) {
+      const int64_t p = 2 * (sg + u) + kh;
+      const bool ok = (sg + u < s1) & (p < a.n);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        x1[u][t] = ok ? a.a1[p * 64 + 32 * t + c] : 0.0f;
+        e2[u][t] = ok ? a.d2[p * 64 + 32 * t + c] : 0.0f;
+        e1[u][t] = ok ? a.d1[p * 64 + 32 * t + c] : 0.0f;
+      }
+      xf[u] = (ok && c < a.K) ? a.fe[p * 32 + c] : 0.0f;
     }
-    const float xf = (ok && c < a.K) ? a.fe[p * 32 + c] : 0.0f;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int u = 0; u < 4; ++u) {
 #pragma unroll
-      for (int to = 0; to < 2; ++to) w1[ti][to] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[ti], e2[to], w1[ti][to], 0, 0, 0);
+      for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-    for (int to = 0; to < 2; ++to) {
-      w0[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(xf, e1[to], w0[to], 0, 0, 0);
-      b1[to] += e2[to];
-      b0[to] += e1[to];
+        for (int to = 0; to < 2; ++to)
+          w1[ti][to] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[u][ti], e2[u][to], w1[ti][to], 0, 0, 0);
+#pragma unroll
+      for (int to = 0; to < 2; ++to) {
+        w0[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[u], e1[u][to], w0[to], 0, 0, 0);
+        b1[to] += e2[u][to];
+        b0[to] += e1[u][to];
+      }
     }
   }
   // output layer: lane = hidden feature, sequential over this wave's points (fixed order)
@@ -202,36 +211,46 @@ __global__ __launch_bounds__(256) void k_wgrad(RcWgradArgs a) {
       bo += g;
     }
   }
-  float* P = a.partial + (int64_t)wave * kPartStride;
+  // the four waves of the workgroup are added in wave order through LDS: one partial per workgroup
+  __shared__ float red[kPartStride];
+  const int wv = threadIdx.x >> 6;
+  for (int turn = 0; turn < 4; ++turn) {
+    if (wv == turn) {
+      auto put = [&](int i, float v) { red[i] = turn == 0 ? v : red[i] + v; };
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
 #pragma unroll
-    for (int to = 0; to < 2; ++to) {
-      P[kPartW0 + m * 64 + 32 * to + c] = w0[to][r];
+        for (int to = 0; to < 2; ++to) {
+          put(kPartW0 + m * 64 + 32 * to + c, w0[to][r]);
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti) P[kPartW1 + (32 * ti + m) * 64 + 32 * to + c] = w1[ti][to][r];
+          for (int ti = 0; ti < 2; ++ti) put(kPartW1 + (32 * ti + m) * 64 + 32 * to + c, w1[ti][to][r]);
+        }
+      }
+#pragma unroll
+      for (int to = 0; to < 2; ++to) {
+        const float sb1 = b1[to] + __shfl_xor(b1[to], 32, 64), sb0 = b0[to] + __shfl_xor(b0[to], 32, 64);
+        if (kh == 0) { put(kPartB1 + 32 * to + c, sb1); put(kPartB0 + 32 * to + c, sb0); }
+      }
+      put(kPartWO + lane, wo);
+      if (lane == 0) put(kPartBO, bo);
     }
+    __syncthreads();
   }
-#pragma unroll
-  for (int to = 0; to < 2; ++to) {
-    const float sb1 = b1[to] + __shfl_xor(b1[to], 32, 64), sb0 = b0[to] + __shfl_xor(b0[to], 32, 64);
-    if (kh == 0) { P[kPartB1 + 32 * to + c] = sb1; P[kPartB0 + 32 * to + c] = sb0; }
-  }
-  P[kPartWO + lane] = wo;
-  if (lane == 0) P[kPartBO] = bo;
+  float* P = a.partial + (int64_t)blockIdx.x * kPartStride;
+  for (int i = threadIdx.x; i <= kPartBO; i += 256) P[i] = red[i];
 }
 
-// grads[.] += sum over waves in a fixed order.  Output layout: [W0 K x 64 | b0 64 | W1 64 x 64 | b1 64 | Wout 64 | bout 1].
+// grads[.] += sum over the workgroup partials in a fixed order.  Output layout: [W0 K x 64 | b0 64 | W1 64 x 64 | b1 64 | Wout 64 | bout 1].
 // A workgroup owns 16 consecutive values; thread (v = tid & 15, s = tid >> 4) adds the partials of waves
-// s, s + 16, ... (64-byte row pieces, many loads in flight), the 16 slices are then added in slice order.
-__global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ partial, int nwaves, int K, float* __restrict__ grads) {
+// s, s + 16, ... of the workgroup partials (64-byte row pieces, many loads in flight), the 16 slices are then added in slice order.
+__global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ partial, int nparts, int K, float* __restrict__ grads) {
   __shared__ float part[16][17];
   const int v = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + v;
   float s = 0.0f;
   if (i <= kPartBO)
-    for (int w = sl; w < nwaves; w += 16) s += partial[(int64_t)w * kPartStride + i];
+    for (int w = sl; w < nparts; w += 16) s += partial[(int64_t)w * kPartStride + i];
   part[sl][v] = s;
   __syncthreads();
   if (sl != 0 || i > kPartBO) return;
@@ -366,7 +385,7 @@ void rc_launch_density_bwd(const RcDensityBwdArgs& a, hipStream_t stream) {
   }
 }
 
-int rc_wgrad_partial_floats(int nwaves) { return nwaves * kPartStride; }
+int rc_wgrad_partial_floats(int nwaves) { return nwaves / 4 * kPartStride; }
 
 // waves: enough to fill the chip once (1024 = 256 CUs x 4 SIMDs), at least 16 k-steps (32 points) each
 int rc_wgrad_waves(int64_t n) {
@@ -384,7 +403,7 @@ void rc_launch_wgrad(RcWgradArgs a, int K, float* grads, hipStream_t stream) {
   a.steps_per_wave = (nsteps + nwaves - 1) / nwaves;
   a.K = K;
   hipLaunchKernelGGL(k_wgrad, dim3(nwaves / 4), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(k_grad_reduce, dim3((kPartBO + 16) / 16), dim3(256), 0, stream, a.partial, nwaves, K, grads);
+  hipLaunchKernelGGL(k_grad_reduce, dim3((kPartBO + 16) / 16), dim3(256), 0, stream, a.partial, nwaves / 4, K, grads);
 }
 
 void rc_launch_grid_scatter(const RcGridScatterArgs& a, hipStream_t stream) {
