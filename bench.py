@@ -170,6 +170,48 @@ def material_line(local_rank, dev, n_rays=1024, steps=5, warmup=2):
             "ms_per_step": ms, "steps": steps}
 
 
+def train_backward_line(local_rank, dev, n_rays=1024, steps=20, warmup=3):
+    """Secondary measurement (not part of `value`): rc_density_backward for the three proposal levels of one 1024-ray
+    batch (64 + 64 + 32 ray-ordered samples per ray): gradients of the hash-grid tables and density MLPs
+    (SURVEY 8(f) rank 4)."""
+    import numpy as np
+    import torch
+
+    import nrc_amd
+    from nrc_amd import rc_ext
+
+    cfg = nrc_amd.hotdog_config()
+    rc = rc_ext.RadianceCache(cfg, local_rank)
+    rc.load_weights(nrc_amd.synthetic_weights(cfg))
+    rng = np.random.Generator(np.random.PCG64(1))
+    rays = nrc_amd.synthetic_rays(n_rays)
+    o = np.asarray(rays.origins)[:, None, :]
+    d = np.asarray(rays.directions)[:, None, :]
+    per_level = {}
+    total_ms = 0.0
+    for level, S in enumerate(lvl[2] for lvl in cfg.sampling_strategy):
+        t = np.linspace(2.0, 6.0, S)[None, :, None] + rng.uniform(0, 4.0 / S, size=(n_rays, 1, 1))
+        n = n_rays * S
+        pts = torch.from_numpy((o + d * t).reshape(n, 3).astype(np.float32)).to(dev)
+        dd = torch.from_numpy(rng.normal(size=(n,)).astype(np.float32)).to(dev)
+        df = torch.from_numpy((rng.normal(size=(n, 64)) * 0.1).astype(np.float32)).to(dev)
+        _, total = rc.density_grad_layout(level)
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        for _ in range(warmup):
+            rc.density_backward(level, pts, dd, df, grads=flat)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rc.density_backward(level, pts, dd, df, grads=flat)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        total_ms += ms
+        per_level[f"level{level}"] = {"samples": n, "ms": ms, "grad_mbytes": total * 4 / 1e6}
+    return {"workload": "backward of the three proposal density fields for one 1024-ray batch (tables + density MLPs)",
+            "rays_per_s": n_rays / (total_ms * 1e-3), "ms_per_step": total_ms, "steps": steps, "levels": per_level,
+            "note": "scatter into the tables is bound by the memory-side atomic request rate (DESIGN.md 4.4)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,6 +222,8 @@ def main():
                     help="skip the secondary measurement of the time-resolved cache (configs[4])")
     ap.add_argument("--no-material", action="store_true",
                     help="skip the secondary measurement of the material stage (configs[2])")
+    ap.add_argument("--no-train", action="store_true",
+                    help="skip the secondary measurement of the density fields' backward pass (SURVEY 8(f) rank 4)")
     ap.add_argument("--graph-mode", type=int, default=2, help="0 eager, 1 lazy hipGraph, 2 hipGraph at once")
     ap.add_argument("--plan", choices=("fused", "staged"), default="fused",
                     help="fused: one launch per batch (rc_set_fused 1, default); staged: one launch per stage")
@@ -315,6 +359,9 @@ def main():
     if not args.no_material and world == 1:
         print("[bench] material line ...", file=sys.stderr, flush=True)
         res["material"] = material_line(local_rank, dev)
+    if not args.no_train and world == 1:
+        print("[bench] train-backward line ...", file=sys.stderr, flush=True)
+        res["train_backward"] = train_backward_line(local_rank, dev)
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline(cfg, weights, RAYS_PER_BATCH)
     else:

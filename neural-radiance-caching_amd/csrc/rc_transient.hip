@@ -311,7 +311,7 @@ constexpr int kTilesB = (kHist + 31) / 32;       // 66 column tiles
 constexpr int kFragsPerTile = 65 + 33;           // SLF output layer (128 + bias) | transient_indirect_layer (64 + bias)
 constexpr int kBinFrags = kTilesB * kFragsPerTile;
 constexpr int kSP = 8;                           // per-sample parameters kept in LDS
-constexpr int kWaveLds = 2 * kHist + kSP * 32 + 6 * 32;   // floats: indirect hist, direct hist, params, bin sums
+constexpr int kWaveLds = 3 * kHist + kSP * 32 + 6 * 32;   // floats: indirect hist (one per half-wave), direct hist, params, bin sums
 
 // softplus on the hardware transcendentals (v_exp_f32 / v_log_f32, about 1 ulp each): the per-bin heads evaluate
 // 2 x 2100 of them per sample, which is what bounds k_transient_bins.  log1p(e) for small e by its series.
@@ -376,14 +376,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
   const int64_t n = a.n_rays * 32;                 // samples
   float* ring = lds_dyn;
   float* wl = lds_dyn + kRingFloats + wave * kWaveLds;
-  float* hist_i = wl;                              // time-shifted indirect histogram
-  float* hist_d = wl + kHist;                      // direct histogram (before the temporal filter)
-  float* sp = wl + 2 * kHist;                      // [kSP][32] per-sample parameters
+  float* hist_i = wl;                              // time-shifted indirect histogram, one per half-wave (added at the end)
+  float* hist_d = wl + 2 * kHist;                  // direct histogram (before the temporal filter)
+  float* sp = wl + 3 * kHist;                      // [kSP][32] per-sample parameters
   float* bsum = sp + kSP * 32;                     // [6][32] per-sample sums over bins (diffuse rgb, specular rgb)
   enum { P_W = 0, P_LDIST, P_CAMDIST, P_TIB0, P_TIB1, P_TIB2, P_DIND, P_KILL };
   WStream ws{a.wstream, ring, lane, wave};
   ws_issue_rt(ws, 0, kBinFrags);
-  for (int e = lane; e < 2 * kHist; e += 64) wl[e] = 0.0f;
+  for (int e = lane; e < 3 * kHist; e += 64) wl[e] = 0.0f;
   if (lane < 32) {
     const int64_t p = ray * 32 + lane;
     const float ld = a.tshade[RC_TS_LDIST * n + p];
@@ -442,6 +442,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
     if (sp[P_KILL * 32 + i] != 0.0f) { lo = kBins; hi = -1; }
     rlo[r] = lo; rhi[r] = hi;
   }
+  float* hist_h = hist_i + h * kHist;
   auto tile_body = [&](const int T, const int u, float (&sdu)[16], float (&ssu)[16]) __attribute__((always_inline)) {
     {
       f32x16 as = zero16(), ai = zero16();
@@ -481,15 +482,13 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
           const float fw = t - i0;
           const float wt = ((int)i0 == b ? 1.0f - fw : 0.0f) + ((int)i0 + 1 == b ? fw : 0.0f);
           const bool ok = live && y >= 0 && y < kBins;
-          // the two half-waves work on different samples and may meet in one entry: one after the other
-          // (within a half-wave the 32 lanes hold 32 different entries of ONE sample: plain read-add-write, which
-          // measured faster than ds_add_f32; the wave barrier keeps the compiler from merging the two phases into
-          // one colliding instruction)
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            if (ok && h == hh) hist_i[y * 3 + c] = hist_i[y * 3 + c] + val * wt;
-            __builtin_amdgcn_wave_barrier();
-          }
+          // the two half-waves work on different samples and may meet in one entry: each adds into its own
+          // histogram.  Within a half-wave the 32 lanes hold 32 different entries of ONE sample: plain
+          // read-add-write (measured faster than ds_add_f32); the k = 1 target of a lane is the k = 0 target of the
+          // lane three entries up, so the two phases stay in order (the wave barrier keeps the compiler from
+          // hoisting the second read above the first write)
+          if (ok) hist_h[y * 3 + c] = hist_h[y * 3 + c] + val * wt;
+          __builtin_amdgcn_wave_barrier();
         }
       }
       cd += __shfl_xor(cd, 32, 64);
@@ -591,7 +590,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
     } else {
       dv = hist_d[e];
     }
-    const float iv = hist_i[e];
+    const float iv = hist_i[e] + hist_i[kHist + e];
     if (ray_ok) {
       if (a.out_rgb) a.out_rgb[ray * kHist + e] = dv + iv;
       if (a.out_direct) a.out_direct[ray * kHist + e] = dv;
