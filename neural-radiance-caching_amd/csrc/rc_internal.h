@@ -262,6 +262,7 @@ struct RcTransShaderArgs {
 
 struct RcTransBinsArgs {
   int64_t n_rays;
+  unsigned long long* stamps;              // diagnostic builds (-DRC_STAMPS) only
   const float* wstream;                    // per column tile: 65 SLF output fragments | 33 transient_indirect fragments
   const float* slf_feat; const float* irr_feat; const float* tshade; const float* weights;   // weights [n_rays][32]
   float exposure, shift, max_dists, irradiance_bias, slf_rgb_bias, indirect_scale, rgb_max, light_near;

@@ -308,17 +308,25 @@ __global__ void k_shadow_rays(RcShadowRayArgs a) {
 constexpr int kBins = 700;
 constexpr int kHist = kBins * 3;                 // 2100 histogram entries per ray, entry = bin * 3 + channel
 constexpr int kTilesB = (kHist + 31) / 32;       // 66 column tiles
-constexpr int kFragsPerTile = 65 + 33;           // SLF output layer (128 + bias) | transient_indirect_layer (64 + bias)
+constexpr int kTileFrags = 65 + 33;              // SLF output layer (128 + bias) | transient_indirect_layer (64 + bias)
+constexpr int kFragsPerTile = 2 * kChunk;        // padded to two whole chunks of the LDS ring: the chunk seams sit at
+                                                 // compile-time positions of a tile (no per-fragment seam test)
+static_assert(kTileFrags <= kFragsPerTile, "a tile's fragments fit its two chunks");
 constexpr int kBinFrags = kTilesB * kFragsPerTile;
-constexpr int kSP = 8;                           // per-sample parameters kept in LDS
-constexpr int kWaveLds = 3 * kHist + kSP * 32 + 6 * 32;   // floats: indirect hist (one per half-wave), direct hist, params, bin sums
+constexpr int kSP = 10;                          // per-sample parameters kept in LDS
+constexpr int kHistPad = kHist + 32;             // + one dummy slot per lane (out-of-range targets read-add-write there)
+constexpr int kMaxTaps = 32;                     // temporal filter taps handled by the unrolled window
+constexpr int kPadD = 3 * (kMaxTaps / 2);        // zeros on both sides of the direct histogram: the filter window needs no range test
+constexpr int kWaveLds = 2 * kHistPad + (kHist + 2 * kPadD) + kSP * 32 + 6 * 32;   // floats: indirect hist (one per half-wave), padded direct hist, params, bin sums
 
 // softplus on the hardware transcendentals (v_exp_f32 / v_log_f32, about 1 ulp each): the per-bin heads evaluate
 // 2 x 2100 of them per sample, which is what bounds k_transient_bins.  log1p(e) for small e by its series.
 __device__ __forceinline__ float softplus_hw(float x) {
-  const float e = __expf(-fabsf(x));
-  const float l = e < 1.0e-3f ? e * (1.0f - 0.5f * e) : __logf(1.0f + e);
-  return fmaxf(x, 0.0f) + l;
+  // straight-line: v_exp_f32 / v_log_f32 are base 2; both forms of log1p are evaluated and selected
+  const float e = __builtin_amdgcn_exp2f(-fabsf(x) * 1.44269504088896341f);
+  const float l = __builtin_amdgcn_logf(1.0f + e) * 0.693147180559945309f;
+  const float s = e * (1.0f - 0.5f * e);
+  return fmaxf(x, 0.0f) + (e < 1.0e-3f ? s : l);
 }
 
 __device__ __forceinline__ void ws_issue_rt(const WStream& w, int c, int nf) {
@@ -333,41 +341,68 @@ __device__ __forceinline__ void ws_issue_rt(const WStream& w, int c, int nf) {
     }
   }
 }
-// fragment f of the stream (f advances by one per call, uniformly over the workgroup)
-__device__ __forceinline__ float ws_next(const WStream& w, int f, int nf) {
-  if (f > 0 && (f & (kChunk - 1)) == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int c = f / kChunk;
-    if ((c + 1) * kChunk < nf) ws_issue_rt(w, c + 1, nf);
+// fragment J of column tile T of the stream.  T is a run-time value, J a constant once the callers' loops are
+// unrolled: a tile is exactly two chunks of the ring, so the seam test folds away and the waits / barriers sit at
+// J = 0 and J = kChunk of every tile
+__device__ __forceinline__ float ws_tile_frag(const WStream& w, int T, int J, int nf) {
+  static_assert(kFragsPerTile == 2 * kChunk, "tile = two chunks");
+  if (J % kChunk == 0) {
+    const int c = 2 * T + J / kChunk;
+    if (c > 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if ((c + 1) * kChunk < nf) ws_issue_rt(w, c + 1, nf);
+    }
   }
-  return w.ring[(f & (2 * kChunk - 1)) * 64 + w.lane];
+  return w.ring[J * 64 + w.lane];
 }
 
-// X W for one column tile: KS k-steps with the activations in registers, fragments [f0, f0 + KS)
-template <int KS>
-__device__ __forceinline__ void tile_xw(const WStream& w, int f0, int nf, const float (&x)[KS], f32x16& acc) {
-  constexpr int SG = 4, NG = (KS + SG - 1) / SG;
-  float b[2][SG];
+// X W of one column tile for both heads: 65 k-steps of the SLF head (xs -> as) and 33 of the irradiance head
+// (xi -> ai).  The two accumulator chains are interleaved 4 : 2 (a chain's next MFMA waits for its previous one; the
+// other chain fills the gap), and the host packs the tile's fragments in exactly this order:
+//   16 groups of [as 4g .. 4g+3 | ai 2g, 2g+1], then [as 64 | ai 32].
+__device__ __forceinline__ void tile_xw2(const WStream& w, int T, int nf, const float (&xs)[65], const float (&xi)[33],
+                                         f32x16& as, f32x16& ai) {
+  constexpr int NG = 17;
+  float b[3][6];                 // operands two groups ahead (three register sets, like mlp_layer)
   auto load = [&](int g, int buf) {
 #pragma unroll
-    for (int d = 0; d < SG; ++d)
-      if (g * SG + d < KS) b[buf][d] = ws_next(w, f0 + g * SG + d, nf);
+    for (int q = 0; q < 6; ++q)
+      if (g < 16 || q < 2) b[buf][q] = ws_tile_frag(w, T, g * 6 + q, nf);
   };
   load(0, 0);
+  load(1, 1);
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    if (g + 1 < NG) load(g + 1, (g + 1) & 1);
+    if (g + 2 < NG) load(g + 2, (g + 2) % 3);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int d = 0; d < SG; ++d)
-      if (g * SG + d < KS) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[g * SG + d], b[g & 1][d], acc, 0, 0, 0);
+    const float (&bb)[6] = b[g % 3];
+    if (g < 16) {
+      as = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[4 * g + 0], bb[0], as, 0, 0, 0);
+      ai = __builtin_amdgcn_mfma_f32_32x32x2f32(xi[2 * g + 0], bb[4], ai, 0, 0, 0);
+      as = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[4 * g + 1], bb[1], as, 0, 0, 0);
+      as = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[4 * g + 2], bb[2], as, 0, 0, 0);
+      ai = __builtin_amdgcn_mfma_f32_32x32x2f32(xi[2 * g + 1], bb[5], ai, 0, 0, 0);
+      as = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[4 * g + 3], bb[3], as, 0, 0, 0);
+    } else {
+      as = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[64], bb[0], as, 0, 0, 0);
+      ai = __builtin_amdgcn_mfma_f32_32x32x2f32(xi[32], bb[1], ai, 0, 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+
+#ifdef RC_STAMPS
+#define RC_BSTAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define RC_BSTAMP(v) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+#ifdef RC_STAMPS
+  const unsigned long long st_kernel_begin = __builtin_amdgcn_s_memtime();
+#endif
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int fl = lane & 31, h = lane >> 5;
   int64_t ray = (int64_t)blockIdx.x * kWaves + wave;
@@ -377,13 +412,13 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
   float* ring = lds_dyn;
   float* wl = lds_dyn + kRingFloats + wave * kWaveLds;
   float* hist_i = wl;                              // time-shifted indirect histogram, one per half-wave (added at the end)
-  float* hist_d = wl + 2 * kHist;                  // direct histogram (before the temporal filter)
-  float* sp = wl + 3 * kHist;                      // [kSP][32] per-sample parameters
+  float* hist_d = wl + 2 * kHistPad + kPadD;       // direct histogram (before the temporal filter), zero padded
+  float* sp = hist_d + kHist + kPadD;              // [kSP][32] per-sample parameters
   float* bsum = sp + kSP * 32;                     // [6][32] per-sample sums over bins (diffuse rgb, specular rgb)
-  enum { P_W = 0, P_LDIST, P_CAMDIST, P_TIB0, P_TIB1, P_TIB2, P_DIND, P_KILL };
+  enum { P_W = 0, P_LDIST, P_CAMDIST, P_TIB0, P_TIB1, P_TIB2, P_DIND, P_KILL, P_LO, P_HI };
   WStream ws{a.wstream, ring, lane, wave};
   ws_issue_rt(ws, 0, kBinFrags);
-  for (int e = lane; e < 3 * kHist; e += 64) wl[e] = 0.0f;
+  for (int e = lane; e < 2 * kHistPad + kHist + 2 * kPadD; e += 64) wl[e] = 0.0f;
   if (lane < 32) {
     const int64_t p = ray * 32 + lane;
     const float ld = a.tshade[RC_TS_LDIST * n + p];
@@ -395,7 +430,26 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
     sp[P_TIB2 * 32 + lane] = a.tshade[(RC_TS_TIB + 2) * n + p];
     // bins_move / exposure_time (render.py:483): ray_dist + shift, divided by the exposure
     sp[P_DIND * 32 + lane] = (a.tshade[RC_TS_RDIST * n + p] + a.shift) / a.exposure;
-    sp[P_KILL * 32 + lane] = (a.light_zero && ld < a.light_near) ? 1.0f : 0.0f;      // render_utils.py:1750-1760
+    const bool kill = a.light_zero && ld < a.light_near;                               // render_utils.py:1750-1760
+    sp[P_KILL * 32 + lane] = kill ? 1.0f : 0.0f;
+    // Window of bins that survive zero_invalid_bins (render_utils.py:1699-1767), once per sample (lane = sample).
+    // Both travel-time tests are monotone in the bin index, so each is a bound: bins >= lo pass
+    // "(b + thr) * e < light_dist" (too close), bins <= hi pass "b * e + cam_dist > max_dists" (too far); the bounds
+    // are settled with the very comparisons of the reference.
+    const float cdist = sp[P_CAMDIST * 32 + lane];
+    auto close = [&](int b) { return (float)(b + a.bin_zero_threshold_light) * a.exposure < ld; };
+    auto far = [&](int b) { return ((float)b * a.exposure + cdist) > a.max_dists; };
+    int lo = (int)ceilf(ld / a.exposure) - a.bin_zero_threshold_light;
+    lo = min(max(lo, 0), kBins);
+    while (lo > 0 && !close(lo - 1)) --lo;
+    while (lo < kBins && close(lo)) ++lo;
+    int hi = (int)floorf((a.max_dists - cdist) / a.exposure);
+    hi = min(max(hi, -1), kBins - 1);
+    while (hi < kBins - 1 && !far(hi + 1)) ++hi;
+    while (hi >= 0 && far(hi)) --hi;
+    if (kill) { lo = kBins; hi = -1; }
+    sp[P_LO * 32 + lane] = __int_as_float(lo);
+    sp[P_HI * 32 + lane] = __int_as_float(hi);
   }
   // activations of the two output layers (this ray's 32 samples), with the bias step
   float xs[65], xi[33];
@@ -408,8 +462,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (kChunk < kBinFrags) ws_issue_rt(ws, 1, kBinFrags);
+#ifdef RC_TMP_PRO
+  unsigned long long st_sync;
+  RC_BSTAMP(st_sync);
+#endif
 
-  const float max_dists = a.max_dists;
   // per-sample sums over the bins: by tile phase u = T % 3 (the channel of a lane's entry is (2 u + fl) % 3)
   float sd[3][16], ss[3][16];
 #pragma unroll
@@ -417,10 +474,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sd[u][r] = 0.0f; ss[u][r] = 0.0f; }
 
-  // Per-sample terms of this lane's 16 samples, kept in registers for all 66 tiles: weight, time shift, and the
-  // window of bins that survive zero_invalid_bins (render_utils.py:1699-1767).  Both travel-time tests are monotone
-  // in the bin index, so each is a bound: bins >= b_lo pass "(b + thr) * e < light_dist" (too close), bins <= b_hi
-  // pass "b * e + cam_dist > max_dists" (too far); the bounds are settled with the very comparisons of the reference.
+  // Per-sample terms of this lane's 16 samples, kept in registers for all 66 tiles: weight, time shift, bin window
   float rw[16], rdm[16];
   int rlo[16], rhi[16];
 #pragma unroll
@@ -428,68 +482,89 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
     const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
     rw[r] = sp[P_W * 32 + i];
     rdm[r] = sp[P_DIND * 32 + i];
-    const float ld = sp[P_LDIST * 32 + i], cdist = sp[P_CAMDIST * 32 + i];
-    auto close = [&](int b) { return (float)(b + a.bin_zero_threshold_light) * a.exposure < ld; };
-    auto far = [&](int b) { return ((float)b * a.exposure + cdist) > max_dists; };
-    int lo = (int)ceilf(ld / a.exposure) - a.bin_zero_threshold_light;
-    lo = min(max(lo, 0), kBins);
-    while (lo > 0 && !close(lo - 1)) --lo;
-    while (lo < kBins && close(lo)) ++lo;
-    int hi = (int)floorf((max_dists - cdist) / a.exposure);
-    hi = min(max(hi, -1), kBins - 1);
-    while (hi < kBins - 1 && !far(hi + 1)) ++hi;
-    while (hi >= 0 && far(hi)) --hi;
-    if (sp[P_KILL * 32 + i] != 0.0f) { lo = kBins; hi = -1; }
-    rlo[r] = lo; rhi[r] = hi;
+    rlo[r] = __float_as_int(sp[P_LO * 32 + i]);
+    rhi[r] = __float_as_int(sp[P_HI * 32 + i]);
   }
-  float* hist_h = hist_i + h * kHist;
+  // value of the tile before, per sample (see the epilogue)
+  float cval[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cval[r] = 0.0f;
+  float* hist_h = hist_i + h * kHistPad;
+#ifdef RC_STAMPS
+  unsigned long long st_mfma = 0, st_epi = 0;
+  const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
   auto tile_body = [&](const int T, const int u, float (&sdu)[16], float (&ssu)[16]) __attribute__((always_inline)) {
     {
+#ifdef RC_STAMPS
+      unsigned long long q0, q1, q2;
+#endif
+      RC_BSTAMP(q0);
       f32x16 as = zero16(), ai = zero16();
-      tile_xw<65>(ws, T * kFragsPerTile, kBinFrags, xs, as);
-      tile_xw<33>(ws, T * kFragsPerTile + 65, kBinFrags, xi, ai);
+      tile_xw2(ws, T, kBinFrags, xs, xi, as, ai);
+      RC_BSTAMP(q1);
       const int f = T * 32 + fl;                   // histogram entry of this lane
       const bool fok = f < kHist;
       const int b = f / 3, c = f - 3 * b;
       float cd = 0.0f, cs = 0.0f;                  // unshifted composites over this half-wave's 16 samples
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        // a sample whose window misses every bin of this tile contributes exact zeros: skip it for the whole wave
+#if defined(RC_ABL) && RC_ABL == 1
+        cd += as[r] + ai[r];      // ablation: MFMAs only
+        continue;
+#endif
+        // A sample whose window misses every bin of this tile contributes exact zeros: skip it for the whole wave
+        // (unless the tile before left it a value to place, see below).
         const bool live = fok && b >= rlo[r] && b <= rhi[r];
-        if (__ballot(live) == 0ull) continue;
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool carry_in = fl >= 29 && cval[r] != 0.0f;
+        if (__ballot(live || carry_in) == 0ull) continue;
         const float w = rw[r];
+        // shift_map_coordinates (render.py:480-496): out[y] = in(y - d), linear, zero outside.  Entry b of this sample
+        // reaches y0 = b + floor(d) and y0 + 1, and y0 also receives the second part of entry b - 1 -- the lane three
+        // entries down (same channel).  Each lane therefore owns ONE target, y0, and adds both parts to it in one
+        // read-add-write of its half-wave's histogram (32 different targets per half-wave and sample; plain
+        // read-add-write measured 2x faster than ds_add_f32).  The read is issued first and the transcendentals
+        // below cover its latency.  The lanes of the first three entries take the neighbour's value from the tile
+        // before (cval); a target outside the histogram goes to the lane's dummy slot.
+        const float dmove = rdm[r];
+        const int y0 = b + (int)floorf(dmove);
+        const bool yok = y0 >= 0 && y0 < kBins;
+        float* slot = hist_h + (yok ? y0 * 3 + c : kHist + fl);
+#if !(defined(RC_ABL) && RC_ABL == 2)
+        const float old = *slot;
+#endif
+        const float tib = sp[(P_TIB0 + c) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
         // nerf.py:1795-1797 and :1712-1719: softplus(. + irradiance_bias) * indirect_scale;
         // surface_light_field.py:1037-1058 and nerf.py:1721-1723: tint * ibrdf * clip(softplus(. + rgb_bias), 0) * scale
+#if defined(RC_ABL) && RC_ABL == 3
+        float diff = (ai[r] + a.irradiance_bias) * a.indirect_scale;       // ablation: no transcendentals
+        const float ref = fmaxf(1.0f * as[r] + a.slf_rgb_bias, 0.0f);
+#else
         float diff = softplus_hw(ai[r] + a.irradiance_bias) * a.indirect_scale;
         const float ref = fmaxf(softplus_hw(1.0f * as[r] + a.slf_rgb_bias), 0.0f);
-        const float tib = sp[(P_TIB0 + c) * 32 + i];
+#endif
         float spec = (tib * ref) * a.indirect_scale;
         diff = live ? fminf(fmaxf(diff, 0.0f), a.rgb_max) : 0.0f;             // nerf.py:1757-1758
         spec = live ? fminf(fmaxf(spec, 0.0f), a.rgb_max) : 0.0f;
         sdu[r] += diff; ssu[r] += spec;
         cd += w * diff; cs += w * spec;
-        // shift_map_coordinates (render.py:480-496): out[y] = in(y - d), linear, zero outside.  Entry b of this
-        // sample reaches y = b + floor(d) and y + 1; the weights are those the target bin computes.
-        const float dmove = rdm[r];
-        const int y0 = b + (int)floorf(dmove);
         const float val = w * (diff + spec);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int y = y0 + k;
-          const float t = (float)y - dmove;
-          const float i0 = floorf(t);
-          const float fw = t - i0;
-          const float wt = ((int)i0 == b ? 1.0f - fw : 0.0f) + ((int)i0 + 1 == b ? fw : 0.0f);
-          const bool ok = live && y >= 0 && y < kBins;
-          // the two half-waves work on different samples and may meet in one entry: each adds into its own
-          // histogram.  Within a half-wave the 32 lanes hold 32 different entries of ONE sample: plain
-          // read-add-write (measured faster than ds_add_f32); the k = 1 target of a lane is the k = 0 target of the
-          // lane three entries up, so the two phases stay in order (the wave barrier keeps the compiler from
-          // hoisting the second read above the first write)
-          if (ok) hist_h[y * 3 + c] = hist_h[y * 3 + c] + val * wt;
-          __builtin_amdgcn_wave_barrier();
-        }
+        const float below = __shfl_up(val, 3, 64);                   // entry f - 3 of this tile (fl >= 3)
+        const float before = __shfl(cval[r], (lane + 29) & 63, 64);  // entry f - 3 of the tile before (fl < 3)
+        const float nb = fl < 3 ? before : below;
+        cval[r] = val;
+        // the weights are those the target bin computes (coordinate y0 - d, floor, linear): wa for entry b, wb for b - 1
+        const float t = (float)y0 - dmove;
+        const float i0 = floorf(t);
+        const float fw = t - i0;
+        const int ii = (int)i0;
+        const float wa = (ii == b ? 1.0f - fw : 0.0f) + (ii + 1 == b ? fw : 0.0f);
+        const float wb = (ii == b - 1 ? 1.0f - fw : 0.0f) + (ii + 1 == b - 1 ? fw : 0.0f);
+#if defined(RC_ABL) && RC_ABL == 2
+        cd += yok ? val * wa + nb * wb : 0.0f;      // ablation: no histogram update
+#else
+        *slot = old + (val * wa + nb * wb);
+#endif
       }
       cd += __shfl_xor(cd, 32, 64);
       cs += __shfl_xor(cs, 32, 64);
@@ -497,6 +572,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
         if (a.out_ti_diffuse) a.out_ti_diffuse[ray * kHist + f] = cd;
         if (a.out_ti_specular) a.out_ti_specular[ray * kHist + f] = cs;
       }
+      RC_BSTAMP(q2);
+#ifdef RC_STAMPS
+      st_mfma += q1 - q0; st_epi += q2 - q1;
+#endif
     }
   };
   for (int T3 = 0; T3 < kTilesB / 3; ++T3) {
@@ -504,6 +583,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
     tile_body(T3 * 3 + 1, 1, sd[1], ss[1]);
     tile_body(T3 * 3 + 2, 2, sd[2], ss[2]);
   }
+#ifdef RC_STAMPS
+  const unsigned long long st_tiles_end = __builtin_amdgcn_s_memtime();
+#endif
   // ---- per-sample sums over the bins: pick the channel of each tile phase, add up the 32 entry lanes
   {
     float v[6][16];
@@ -534,6 +616,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
     }
   }
   lds_sync<false>();
+#ifdef RC_STAMPS
+  unsigned long long st_t1, st_t2;
+  RC_BSTAMP(st_t1);
+#endif
   // ---- direct light: scatter at (ray_dist + light_dist) / exposure with floor / ceil weights (render.py:436-477).
   //      The reference indexes the flattened [rays * bins] array: bins >= 700 of the previous ray of the batch
   //      land at the start of this ray's histogram.
@@ -575,23 +661,50 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
     }
   }
   lds_sync<false>();
+#ifdef RC_STAMPS
+  RC_BSTAMP(st_t2);
+#endif
   // ---- temporal filter on the direct part (render.py:406-417), outputs, sums over bins
   float sum_d[3] = {0.0f, 0.0f, 0.0f}, sum_i[3] = {0.0f, 0.0f, 0.0f};
+  // the taps in registers (wave-uniform loads); the window of an entry is n_taps LDS reads 3 floats apart around it,
+  // the zero padding of hist_d stands in for the bins outside [0, 700) (adding tap * 0 leaves the sum unchanged)
+  float tp[kMaxTaps];
+#pragma unroll
+  for (int k = 0; k < kMaxTaps; ++k) tp[k] = k < a.n_taps ? a.taps[k] : 0.0f;
+  const int half_taps = (a.n_taps - 1) / 2;
   for (int e = lane; e < kHist; e += 64) {
     const int b = e / 3, c = e - 3 * b;
     float dv;
-    if (a.n_taps > 0) {
+    if (a.n_taps > kMaxTaps) {
       dv = 0.0f;
-      const int half = (a.n_taps - 1) / 2;
       for (int k = 0; k < a.n_taps; ++k) {
-        const int yb = b - (k - half);
+        const int yb = b - (k - half_taps);
         if (yb >= 0 && yb < kBins) dv += a.taps[k] * hist_d[yb * 3 + c];
+      }
+#if defined(RC_ABL) && RC_ABL == 6
+    } else if (a.n_taps < 0) {                   // ablation: no filter
+#else
+    } else if (a.n_taps > 0) {
+#endif
+      dv = 0.0f;
+      const float* win = hist_d + e + 3 * half_taps;        // tap k reads bin b - (k - half)
+      if (a.n_taps == 25) {
+#pragma unroll
+        for (int k = 0; k < 25; ++k) dv += tp[k] * win[-3 * k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < kMaxTaps; ++k)
+          if (k < a.n_taps) dv += tp[k] * win[-3 * k];
       }
     } else {
       dv = hist_d[e];
     }
-    const float iv = hist_i[e] + hist_i[kHist + e];
+    const float iv = hist_i[e] + hist_i[kHistPad + e];
+#if defined(RC_ABL) && RC_ABL == 5
+    if (ray_ok && dv + iv == 12345.678f) {       // ablation: no output stores
+#else
     if (ray_ok) {
+#endif
       if (a.out_rgb) a.out_rgb[ray * kHist + e] = dv + iv;
       if (a.out_direct) a.out_direct[ray * kHist + e] = dv;
       if (a.out_indirect) a.out_indirect[ray * kHist + e] = iv;
@@ -652,6 +765,16 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
       st3(a.out_light_radiance_rgb, v[E_W], v[E_W], v[E_W]);    // light_radiance_mult == 1 (nerf.py:1118)
     }
   }
+#ifdef RC_STAMPS
+  if (lane == 0 && ray_ok && a.stamps) {
+    unsigned long long* d = a.stamps + ray * 8;
+    d[0] = st_begin; d[1] = st_mfma; d[2] = st_epi; d[3] = st_tiles_end; d[4] = __builtin_amdgcn_s_memtime();
+    d[5] = st_kernel_begin; d[6] = st_t1; d[7] = st_t2;
+#ifdef RC_TMP_PRO
+    d[6] = st_sync;
+#endif
+  }
+#endif
 }
 
 }  // namespace
@@ -675,8 +798,18 @@ void rc_launch_transient_shader(const RcTransShaderArgs& a, hipStream_t stream) 
   hipLaunchKernelGGL(k_transient_shader, dim3((unsigned)((ntiles + kWaves - 1) / kWaves)), dim3(kWaves * 64), lds, stream, a);
 }
 
-void rc_launch_transient_bins(const RcTransBinsArgs& a, hipStream_t stream) {
+#ifdef RC_STAMPS
+static unsigned long long* g_bins_stamps = nullptr;
+extern "C" void* rc_debug_bins_stamps() { return g_bins_stamps; }
+#endif
+
+void rc_launch_transient_bins(const RcTransBinsArgs& a0, hipStream_t stream) {
+  RcTransBinsArgs a = a0;
   if (a.n_rays <= 0) return;
+#ifdef RC_STAMPS
+  if (!g_bins_stamps) (void)hipMalloc((void**)&g_bins_stamps, (size_t)65536 * 8 * sizeof(unsigned long long));
+  a.stamps = a.n_rays <= 65536 ? g_bins_stamps : nullptr;
+#endif
   static std::atomic<uint64_t> prepared{0};
   const int lds = (kRingFloats + kWaves * kWaveLds) * (int)sizeof(float);
   if (rc_first_use_on_device(prepared)) {
