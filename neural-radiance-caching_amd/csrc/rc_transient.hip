@@ -462,10 +462,6 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (kChunk < kBinFrags) ws_issue_rt(ws, 1, kBinFrags);
-#ifdef RC_TMP_PRO
-  unsigned long long st_sync;
-  RC_BSTAMP(st_sync);
-#endif
 
   // per-sample sums over the bins: by tile phase u = T % 3 (the channel of a lane's entry is (2 u + fl) % 3)
   float sd[3][16], ss[3][16];
@@ -494,6 +490,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
   unsigned long long st_mfma = 0, st_epi = 0;
   const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
 #endif
+  // A tile = its 98 MFMAs, then its epilogue.  Running the epilogue of tile T next to the MFMAs of tile T + 1 in one
+  // straight-line block was tried and is slower: at one wave per SIMD a wave's own VALU work does not run in the shadow
+  // of its MFMAs on gfx950 (tools/micro/mfma_valu_overlap.hip: interleaved = 85 % of the sum), it takes a second wave.
   auto tile_body = [&](const int T, const int u, float (&sdu)[16], float (&ssu)[16]) __attribute__((always_inline)) {
     {
 #ifdef RC_STAMPS
@@ -770,9 +769,6 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
     unsigned long long* d = a.stamps + ray * 8;
     d[0] = st_begin; d[1] = st_mfma; d[2] = st_epi; d[3] = st_tiles_end; d[4] = __builtin_amdgcn_s_memtime();
     d[5] = st_kernel_begin; d[6] = st_t1; d[7] = st_t2;
-#ifdef RC_TMP_PRO
-    d[6] = st_sync;
-#endif
   }
 #endif
 }

@@ -30,5 +30,3 @@ print(f"  tiles: MFMA     {med(d[:, 1]):10.0f}   ({med(d[:, 1]) / 66:.0f} per ti
 print(f"  tiles: epilogue {med(d[:, 2]):10.0f}   ({med(d[:, 2]) / 66:.0f} per tile)")
 print(f"  tiles: other    {med(d[:, 3] - d[:, 0] - d[:, 1] - d[:, 2]):10.0f}")
 print(f"  tail            {med(d[:, 4] - d[:, 3]):10.0f}   (bin sums {med(d[:, 6] - d[:, 3]):.0f}, direct scatter {med(d[:, 7] - d[:, 6]):.0f}, filter + outputs + extras {med(d[:, 4] - d[:, 7]):.0f})")
-if os.environ.get("RC_TMP_PRO"):
-    print(f"  prologue until first sync {med(d[:, 6] - d[:, 5]):.0f}")
