@@ -36,41 +36,44 @@ struct WStream {
 };
 
 // Issue the LDS-DMA of chunk c (this wave's quarter: 4 x 1 KiB).
-template <int NF, int W = kWaves>
+// CH: fragments per chunk of this kernel's ring (kChunk unless LDS is short: the EnvMap kernel runs 4 waves with a
+// 2 x 8 KiB ring).
+template <int NF, int W = kWaves, int CH = kChunk>
 __device__ __forceinline__ void ws_issue(const WStream& w, int c) {
+  static_assert(CH % (4 * W) == 0, "whole 1-KiB pieces per wave");
 #pragma unroll
-  for (int k = 0; k < kChunk / 4 / W; ++k) {
+  for (int k = 0; k < CH / 4 / W; ++k) {
     const int i = w.wave + W * k;                  // 1-KiB piece inside the chunk
-    const int frag0 = c * kChunk + 4 * i;
+    const int frag0 = c * CH + 4 * i;
     if (frag0 < NF) {
       const float* src = w.g + (size_t)frag0 * 64 + w.lane * 4;
-      float* dst = w.ring + ((c & 1) * kChunk + 4 * i) * 64;
+      float* dst = w.ring + ((c & 1) * CH + 4 * i) * 64;
       __builtin_amdgcn_global_load_lds((const void*)src, (lds_void_ptr)dst, 16, 0, 0);
     }
   }
 }
 
-template <int NF, int W = kWaves>
+template <int NF, int W = kWaves, int CH = kChunk>
 __device__ __forceinline__ void ws_begin(const WStream& w) {
-  ws_issue<NF, W>(w, 0);
+  ws_issue<NF, W, CH>(w, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (kChunk < NF) ws_issue<NF, W>(w, 1);
+  if (CH < NF) ws_issue<NF, W, CH>(w, 1);
 }
 
 // Entering chunk c: it has landed (issued one chunk ago), everybody is done with chunk c-1.
-template <int NF, int W = kWaves>
+template <int NF, int W = kWaves, int CH = kChunk>
 __device__ __forceinline__ void ws_advance(const WStream& w, int c) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if ((c + 1) * kChunk < NF) ws_issue<NF, W>(w, c + 1);
+  if ((c + 1) * CH < NF) ws_issue<NF, W, CH>(w, c + 1);
 }
 
 // Read fragment f of the stream as a per-lane value (used for lane-layout constant vectors).
-template <int NF, int W = kWaves>
+template <int NF, int W = kWaves, int CH = kChunk>
 __device__ __forceinline__ float ws_read(const WStream& w, int f) {
-  if (f > 0 && f % kChunk == 0) ws_advance<NF, W>(w, f / kChunk);
-  return w.ring[(f % (2 * kChunk)) * 64 + w.lane];
+  if (f > 0 && f % CH == 0) ws_advance<NF, W, CH>(w, f / CH);
+  return w.ring[(f % (2 * CH)) * 64 + w.lane];
 }
 
 // One pass over KS k-steps for NT output tiles; the layer's fragments are [FBASE, FBASE + KS*NT)
@@ -78,7 +81,7 @@ __device__ __forceinline__ float ws_read(const WStream& w, int f) {
 // Software pipelined in groups of SG k-steps: the LDS reads (A fragments + B activations) of group
 // g+1 are issued before the MFMAs of group g, with scheduling fences so they stay there; the MFMA
 // pipe then runs back to back while the next operands are in flight.
-template <int NT, int KS, int FBASE, int NF, int SG = (NT >= 8 ? 1 : (NT >= 4 ? 2 : (NT >= 2 ? 4 : 8))), int W = kWaves>
+template <int NT, int KS, int FBASE, int NF, int SG = (NT >= 8 ? 1 : (NT >= 4 ? 2 : (NT >= 2 ? 4 : 8))), int W = kWaves, int CH = kChunk>
 __device__ __forceinline__ void mlp_layer(const WStream& w, const float* act, f32x16 (&acc)[NT]) {
   constexpr int NG = (KS + SG - 1) / SG;
   float a[3][SG][NT], b[3][SG];
@@ -91,8 +94,8 @@ __device__ __forceinline__ void mlp_layer(const WStream& w, const float* act, f3
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int f = FBASE + s * NT + t;            // compile-time after unrolling
-          if (f > 0 && f % kChunk == 0) ws_advance<NF, W>(w, f / kChunk);
-          a[buf][d][t] = w.ring[(f % (2 * kChunk)) * 64 + w.lane];
+          if (f > 0 && f % CH == 0) ws_advance<NF, W, CH>(w, f / CH);
+          a[buf][d][t] = w.ring[(f % (2 * CH)) * 64 + w.lane];
         }
       }
     }

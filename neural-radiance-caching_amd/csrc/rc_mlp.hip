@@ -234,11 +234,13 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_shader(RcShaderArgs a) {
 // -> concat input (283) -> 128 -> rgba; rgb = clip(softplus(raw + rgb_bias), 0, inf).
 // Replaces Model._handle_env_map -> SurfaceLightFieldMLP.__call__ as configured by
 // NeRFModel.env_map_params (internal/models.py:360-421, internal/surface_light_field.py:480-499,
-// 1011-1058, internal/coord.py:298-312).  One wave = 32 rays; 2 waves per workgroup (the 256-wide
-// activations need 129 LDS steps per wave).
+// 1011-1058, internal/coord.py:298-312).  One wave = 32 rays.  The 256-wide activations need 129 LDS steps per wave
+// (33 KiB): four waves (one per SIMD) fit next to a ring of 2 x 8 KiB chunks (149 KiB), not next to the usual 32 KiB one.
 // ---------------------------------------------------------------------------------------------
-constexpr int kEnvWaves = 2;
+constexpr int kEnvWaves = 4;
 constexpr int kEnvActSteps = 130;
+constexpr int kEnvChunk = 32;                        // fragments per chunk of this kernel's ring
+constexpr int kEnvRingFloats = 2 * kEnvChunk * 64;
 
 __global__ __launch_bounds__(kEnvWaves * 64) void k_envmap(RcEnvMapArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
@@ -252,9 +254,9 @@ __global__ __launch_bounds__(kEnvWaves * 64) void k_envmap(RcEnvMapArgs a) {
   const bool valid = p < a.n;
   const int64_t pc = valid ? p : a.n - 1;
   float* ring = lds_dyn;
-  float* act = lds_dyn + kRingFloats + wave * (kEnvActSteps * 64) + lane;
+  float* act = lds_dyn + kEnvRingFloats + wave * (kEnvActSteps * 64) + lane;
   WStream ws{a.wstream, ring, lane, wave};
-  ws_begin<NF, kEnvWaves>(ws);
+  ws_begin<NF, kEnvWaves, kEnvChunk>(ws);
 
   // pos_enc(x, 0, 4, append_identity): [x(3), sin(2^j x)(12), sin(2^j x + pi/2)(12)]
   const float d[3] = {a.viewdirs[3 * pc], a.viewdirs[3 * pc + 1], a.viewdirs[3 * pc + 2]};
@@ -274,29 +276,29 @@ __global__ __launch_bounds__(kEnvWaves * 64) void k_envmap(RcEnvMapArgs a) {
   f32x16 acc[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = zero16();
-  mlp_layer<8, KS_IN, F_E0, NF, 1, kEnvWaves>(ws, act, acc);
+  mlp_layer<8, KS_IN, F_E0, NF, 1, kEnvWaves, kEnvChunk>(ws, act, acc);
   park<8, true>(acc, act, 0);
   act[128 * 64] = h == 0 ? 1.0f : 0.0f;
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = zero16();
-  mlp_layer<8, 129, F_E1, NF, 1, kEnvWaves>(ws, act, acc);
+  mlp_layer<8, 129, F_E1, NF, 1, kEnvWaves, kEnvChunk>(ws, act, acc);
   park<8, true>(acc, act, 0);
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = zero16();
-  mlp_layer<8, 129, F_E2, NF, 1, kEnvWaves>(ws, act, acc);
+  mlp_layer<8, 129, F_E2, NF, 1, kEnvWaves, kEnvChunk>(ws, act, acc);
   park<8, true>(acc, act, 0);
   // layer_bottleneck on concat([x2 (256), inputs (27)]): x part, then the re-staged input part (+bias)
   f32x16 bt[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) bt[t] = zero16();
-  mlp_layer<4, 128, F_EB, NF, 2, kEnvWaves>(ws, act, bt);
+  mlp_layer<4, 128, F_EB, NF, 2, kEnvWaves, kEnvChunk>(ws, act, bt);
   stage_inputs();
-  mlp_layer<4, KS_IN, F_EI, NF, 2, kEnvWaves>(ws, act, bt);
+  mlp_layer<4, KS_IN, F_EI, NF, 2, kEnvWaves, kEnvChunk>(ws, act, bt);
   park<4, true>(bt, act, 0);
   act[64 * 64] = h == 0 ? 1.0f : 0.0f;
   f32x16 o[1];
   o[0] = zero16();
-  mlp_layer<1, 65, F_EO, NF, 8, kEnvWaves>(ws, act, o);
+  mlp_layer<1, 65, F_EO, NF, 8, kEnvWaves, kEnvChunk>(ws, act, o);
   if (h == 0 && valid) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) a.env_rgb[3 * p + c] = fmaxf(softplus(o[0][c] + a.rgb_bias), 0.0f);
@@ -342,7 +344,7 @@ void rc_launch_shader(const RcShaderArgs& a, hipStream_t stream) {
 void rc_launch_envmap(const RcEnvMapArgs& a, hipStream_t stream) {
   if (a.n <= 0) return;
   static std::atomic<uint64_t> prepared{0};
-  const int lds = (kRingFloats + kEnvWaves * kEnvActSteps * 64) * (int)sizeof(float);
+  const int lds = (kEnvRingFloats + kEnvWaves * kEnvActSteps * 64) * (int)sizeof(float);
   if (rc_first_use_on_device(prepared)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_envmap), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }

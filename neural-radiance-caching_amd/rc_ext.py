@@ -330,6 +330,17 @@ class RadianceCache:
         self._check(self.lib.rc_load_weights(self._h, descs, len(weights)))
 
     # -- hot path ---------------------------------------------------------------------------
+    def _zeros_like_many(self, shapes):
+        """Zero-filled float32 cuda tensors of the given shapes as views of ONE allocation (one fill kernel instead of
+        one per output; every view starts on a 256-byte boundary)."""
+        torch = self._torch
+        offs, total = [], 0
+        for shp in shapes:
+            offs.append(total)
+            total += (int(np.prod(shp)) + 63) // 64 * 64
+        flat = torch.zeros(max(total, 1), dtype=torch.float32, device=f"cuda:{self.device}")
+        return [flat[o: o + int(np.prod(shp))].view(shp) for o, shp in zip(offs, shapes)]
+
     def _dev(self, x, dtype=None):
         torch = self._torch
         dtype = dtype or torch.float32
@@ -381,10 +392,11 @@ class RadianceCache:
         cout = rc_outputs()
         res = {}
         dev = f"cuda:{self.device}"
+        shapes = {nm: ((n, 3) if OUTPUTS[OUTPUT_ID[nm]][1] == 3 else (n,)) for nm in names}
+        fresh = dict(zip(names, self._zeros_like_many([shapes[nm] for nm in names]))) if out is None else None
         for nm in names:
-            width = OUTPUTS[OUTPUT_ID[nm]][1]
-            shape = (n, 3) if width == 3 else (n,)
-            t = out[nm] if out is not None else torch.zeros(shape, dtype=torch.float32, device=dev)
+            shape = shapes[nm]
+            t = out[nm] if out is not None else fresh[nm]
             if tuple(t.shape) != shape or not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
                 raise ValueError(f"output buffer {nm}: expected contiguous float32 cuda tensor of shape {shape}")
             res[nm] = t
@@ -541,11 +553,12 @@ class RadianceCache:
         res = {}
         dev = f"cuda:{self.device}"
         nb = self.cfg.transient.n_bins
-        for nm in names:
+        def tshape(nm):
             kind = TRANSIENT_OUTPUTS[TRANSIENT_OUTPUT_ID[nm]][1]
-            shape = (n, nb, 3) if kind == "bins" else ((n, 3) if kind == 3 else (n,))
-            res[nm] = torch.zeros(shape, dtype=torch.float32, device=dev)
-            cout.ptr[TRANSIENT_OUTPUT_ID[nm]] = res[nm].data_ptr()
+            return (n, nb, 3) if kind == "bins" else ((n, 3) if kind == 3 else (n,))
+        for nm, t in zip(names, self._zeros_like_many([tshape(nm) for nm in names])):
+            res[nm] = t
+            cout.ptr[TRANSIENT_OUTPUT_ID[nm]] = t.data_ptr()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         self._check(self.lib.rc_render_transient(self._h, C.byref(r), cam.data_ptr(), n, rnd_p, shadow_p, C.byref(cout), stream))
         self._keep = [held]
@@ -580,14 +593,15 @@ class RadianceCache:
         mr.sec_gumbel = held["sg"].data_ptr()
         cout, mout = rc_outputs(), rc_mat_outputs()
         cres, mres = {}, {}
-        for i, (nm, width) in enumerate(OUTPUTS):
-            if nm in ("env_map_rgb", "rgb_no_env"):
-                continue
-            cres[nm] = torch.zeros((n, 3) if width == 3 else (n,), dtype=torch.float32, device=dev)
-            cout.ptr[i] = cres[nm].data_ptr()
-        for i, (nm, width) in enumerate(MAT_OUTPUTS):
-            mres[nm] = torch.zeros((n, 3) if width == 3 else (n,), dtype=torch.float32, device=dev)
-            mout.ptr[i] = mres[nm].data_ptr()
+        c_items = [(i, nm, width) for i, (nm, width) in enumerate(OUTPUTS) if nm not in ("env_map_rgb", "rgb_no_env")]
+        m_items = [(i, nm, width) for i, (nm, width) in enumerate(MAT_OUTPUTS)]
+        bufs = self._zeros_like_many([((n, 3) if width == 3 else (n,)) for _, _, width in c_items + m_items])
+        for (i, nm, _), t in zip(c_items, bufs[: len(c_items)]):
+            cres[nm] = t
+            cout.ptr[i] = t.data_ptr()
+        for (i, nm, _), t in zip(m_items, bufs[len(c_items):]):
+            mres[nm] = t
+            mout.ptr[i] = t.data_ptr()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         self._check(self.lib.rc_render_material(self._h, C.byref(r), n, C.byref(rnd), C.byref(mr), K, C.byref(cout),
                                                 C.byref(mout), stream))
