@@ -155,14 +155,23 @@ __global__ __launch_bounds__(128) void k_light_head(RcLightHeadArgs a) {
   __syncthreads();
   if (t < 64) {
     float acc = 0.0f;
+#pragma unroll 16
     for (int i = 0; i < 64; ++i) acc = acc + s_h0[i] * a.w1[i * 64 + t];
     s_h1[t] = fmaxf(acc + a.b1[t], 0.0f);
   }
   __syncthreads();
-  for (int o = t; o < 640; o += 128) {
-    float acc = 0.0f;
-    for (int i = 0; i < 64; ++i) acc = acc + s_h1[i] * a.w2[i * 640 + o];
-    s_p[o] = acc + a.b2[o];
+  {
+    // the thread's five outputs side by side: five independent load / FMA chains per step instead of one (each
+    // output still adds its 64 products in the same order)
+    float acc[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) {
+      const float hv = s_h1[i];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) acc[k] = acc[k] + hv * a.w2[i * 640 + t + 128 * k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s_p[t + 128 * k] = acc[k] + a.b2[t + 128 * k];
   }
   __syncthreads();
   // lobe t (128 lobes): get_vmfs (light_sampler.py:135-160) then LightSampler's l2_normalize / softmax
@@ -201,13 +210,16 @@ __device__ __forceinline__ float eval_vmf(V3 x, V3 mean, float kappa) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_brdf_sample(RcBrdfSampleArgs a) {
   __shared__ float s_vmf[4][128 * RC_VMF_CH];
+  __shared__ float s_den[4][128];        // 4 pi sinh(kappa) per lobe: the direction-independent part of eval_vmf
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int64_t r = (int64_t)blockIdx.x * 4 + wave;
   const bool ok = r < a.n;
   if (!ok) r = a.n - 1;
   for (int i = lane; i < 128 * RC_VMF_CH; i += 64) s_vmf[wave][i] = a.vmf[r * 128 * RC_VMF_CH + i];
+  for (int j = lane; j < 128; j += 64) s_den[wave][j] = 4.0f * kPi * sinhf(a.vmf[(r * 128 + j) * RC_VMF_CH + 3]);
   __syncthreads();
   const float* vm = s_vmf[wave];
+  const float* den = s_den[wave];
   const int Ks = a.Ks, Kd = a.Kd, Kc = a.Kc, K = Ks + Kd;
   const V3 nrm = {a.nrm[3 * r], a.nrm[3 * r + 1], a.nrm[3 * r + 2]};
   const V3 pt = {a.pts[3 * r], a.pts[3 * r + 1], a.pts[3 * r + 2]};
@@ -219,7 +231,11 @@ __global__ __launch_bounds__(256) void k_brdf_sample(RcBrdfSampleArgs a) {
     float s = 0.0f;
     for (int j = 0; j < 128; ++j) {
       const float* q = vm + j * RC_VMF_CH;
-      s = s + q[4] * eval_vmf(gdir, V3{q[0], q[1], q[2]}, q[3]);
+      // eval_vmf with its denominator 4 pi sinh(kappa) taken from the per-lobe table (same operations, same order)
+      const float kappa = q[3];
+      const float e = kappa <= RC_EPS ? 1.0f / (4.0f * kPi)
+                                      : kappa * expf(fminf(kappa * dot(gdir, V3{q[0], q[1], q[2]}), 80.0f)) / den[j];
+      s = s + q[4] * e;
     }
     return fmaxf(s, 0.0f);
   };

@@ -1,4 +1,4 @@
-import sys
-sys.path.insert(0, ".")
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 print(bench.material_line(0, torch.device("cuda:0")))

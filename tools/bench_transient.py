@@ -1,5 +1,5 @@
-import sys, time
-sys.path.insert(0, ".")
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 print(bench.transient_line(0, torch.device("cuda:0")))
