@@ -545,6 +545,7 @@ int repack(rc_handle* h) {
           if (g < 2) {
             if ((rc = cells("cell" + std::to_string(g) + "_" + std::to_string(l), ncell * 8, &dst))) return rc;
             rc_launch_build_cells(L.table, L.size, 1, dst, 1, 0, nullptr);
+            h->grids[g].dev.lvl[l].cell = dst;       // the launch-per-stage gather reads it as well
           } else {
             if ((rc = cells("pair_" + std::to_string(l), ncell * 64, &dst))) return rc;      // replaces the flat pair table
             rc_launch_build_cells(L.table, L.size, 4, dst, 8, 0, nullptr);
@@ -812,6 +813,7 @@ int rc_load_weights(rc_handle* h, const rc_tensor_desc* descs, int32_t n) {
         if (!b.p) { RC_HIP(h, hipMalloc((void**)&b.p, bytes)); b.bytes = bytes; }
         RC_HIP(h, hipMemcpy(b.p, d.data, bytes, d.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
         gs.dev.lvl[l].table = b.p;
+        gs.dev.lvl[l].cell = nullptr;    // the derived cell table is stale until the next repack
         gs.loaded[l] = true;
         h->packed_dirty = true;          // derived device copies (interleaved level-2 tables) follow the tables
         handled = true;

@@ -191,6 +191,14 @@ template <int F, bool JAC>
 __device__ __forceinline__ void grid_level(const RcGridLevel& L, float bbox, float x, float y, float z, float (&acc)[F],
                                            float (&jacc)[JAC ? 3 * F : 1]) {
   Corners<F> C;
+  if constexpr (F == 1 && !JAC) {
+    // one contiguous 32-byte read per cell instead of eight scattered corners (wave-uniform branch: blockIdx.y = level)
+    if (L.cell) {
+      grid_fetch<1, false, 1, true>(L.cell, L.size, L.mask, L.entries, true, unit_box(bbox, x), unit_box(bbox, y), unit_box(bbox, z), C);
+      grid_combine<F, JAC>(C, acc, jacc);
+      return;
+    }
+  }
   grid_fetch<F>(L.table, L.size, L.mask, L.entries, L.dense != 0, unit_box(bbox, x), unit_box(bbox, y), unit_box(bbox, z), C);
   grid_combine<F, JAC>(C, acc, jacc);
 }

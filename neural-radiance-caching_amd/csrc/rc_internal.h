@@ -23,6 +23,8 @@ struct RcGridLevel {
   int32_t dense;        // 1: dense grid, 0: hash table
   uint32_t entries;     // N^3 or T
   uint32_t mask;        // T-1 if T is a power of two, else 0
+  const float* cell;    // dense F = 1 levels of the proposal grids: cell table ((N+3)^3 cells x 8 corners, zero padding
+                        // baked in; built with the fused kernel's tables) or nullptr
 };
 
 struct RcGridDev {
