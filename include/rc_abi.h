@@ -332,6 +332,8 @@ typedef struct rc_camera {
   float camtoworld[12];  /* extrinsics, row-major [3,4]                                                  */
   float light[3];        /* lights[cam_idx] (camera_utils.py:1288)                                       */
   float near, far;       /* Pixels.near / Pixels.far                                                     */
+  int32_t camtype;       /* 0 ProjectionType.PERSPECTIVE, 1 PANORAMIC (cast_spherical_rays, camera_utils.py:1415-1443,
+                          * 1013-1024: pixtocam = diag(2 pi / W, pi / H, 1), (theta, phi) -> direction)           */
 } rc_camera;
 typedef struct rc_cast_outputs {
   float* origins; float* directions; float* viewdirs;   /* [n,3] */

@@ -31,6 +31,15 @@ class Camera:
     light: Optional[np.ndarray] = None   # [3]; default: the camera centre (datasets.py:1348)
     near: float = 2.0
     far: float = 6.0
+    camtype: str = "perspective"       # ProjectionType value: "perspective" or "pano"
+
+
+def cast_spherical_rays(rc, camtoworld, height: int, width: int, near: float, far: float, light=None) -> Rays:
+    """camera_utils.cast_spherical_rays (internal/camera_utils.py:1415-1443): the full [height, width] panorama around
+    `camtoworld`, pixtocam = diag(2 pi / width, pi / height, 1), ProjectionType.PANORAMIC."""
+    p2c = np.diag(np.array([2.0 * np.pi / width, np.pi / height, 1.0]))
+    cam = Camera(pixtocam=p2c, camtoworld=np.asarray(camtoworld)[:3, :4], light=light, near=near, far=far, camtype="pano")
+    return rc.cast_rays(cam, rect=(0, 0, width, height))
 
 
 def cast_ray_batch(rc, camera: Camera, pix_x_int=None, pix_y_int=None, rect=None) -> Rays:

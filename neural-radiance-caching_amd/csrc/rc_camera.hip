@@ -1,8 +1,8 @@
-// On-device ray generation for pinhole cameras.
+// On-device ray generation for pinhole and panoramic cameras.
 //
 // Replaces camera_utils.pixels_to_rays (internal/camera_utils.py:896-1072) + cast_ray_batch (:1225-1329) for the
-// configuration of the BASELINE scenes: ProjectionType.PERSPECTIVE, no distortion, no NDC, no z_range, no pixel
-// jitter, one camera per call.  Same arithmetic in the same order: pixel centre (x + 0.5, y + 0.5, 1) and its
+// configuration of the BASELINE scenes: ProjectionType.PERSPECTIVE (and PANORAMIC = cast_spherical_rays, :1415-1443, the
+// secondary-ray visualisation), no distortion, no NDC, no z_range, no pixel jitter, one camera per call.  Same arithmetic in the same order: pixel centre (x + 0.5, y + 0.5, 1) and its
 // +1 neighbours in x and y through pixtocam, flip to OpenGL axes (y, z negated), rotate by camtoworld[:3, :3],
 // viewdirs = directions / |directions|, radii = 0.5 (|dx - d| + |dy - d|) * 2 / sqrt(12).
 #include "rc_internal.h"
@@ -31,6 +31,13 @@ __global__ void k_cast_rays(RcCastArgs a) {
     const float x = (float)(px + (k == 1 ? 1 : 0)) + 0.5f, y = (float)(py + (k == 2 ? 1 : 0)) + 0.5f;
     float cx, cy, cz;
     mat3_vec(a.pixtocam, x, y, 1.0f, cx, cy, cz);
+    if (a.camtype == 1) {
+      // ProjectionType.PANORAMIC (camera_utils.py:1013-1024): (theta, phi) = the first two components
+      const float theta = cx, phi = cy;
+      cx = -sinf(phi) * sinf(theta);
+      cy = -cosf(phi);
+      cz = -sinf(phi) * cosf(theta);
+    }
     // OpenCV -> OpenGL: diag(1, -1, -1)
     cy = -cy; cz = -cz;
     if (k == 0 && a.imageplane) { a.imageplane[2 * i] = cx; a.imageplane[2 * i + 1] = cy; }

@@ -300,6 +300,7 @@ struct RcCastArgs {
   int32_t x0, y0, width;
   float pixtocam[9]; float rot[9]; float trans[3]; float light[3];
   float near_v, far_v;
+  int32_t camtype;                                  // 0 perspective, 1 panoramic
   float* origins; float* directions; float* viewdirs; float* radii; float* imageplane; float* look; float* up;
   float* lights; float* near; float* far;
 };

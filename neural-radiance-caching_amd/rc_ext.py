@@ -131,7 +131,7 @@ class rc_transient_outputs(C.Structure):
 
 class rc_camera(C.Structure):
     _fields_ = [("pixtocam", C.c_float * 9), ("camtoworld", C.c_float * 12), ("light", C.c_float * 3),
-                ("near", C.c_float), ("far", C.c_float)]
+                ("near", C.c_float), ("far", C.c_float), ("camtype", C.c_int32)]
 
 
 CAST_OUTPUTS = (("origins", 3), ("directions", 3), ("viewdirs", 3), ("radii", 1), ("imageplane", 2), ("look", 3), ("up", 3),
@@ -498,6 +498,7 @@ class RadianceCache:
         for i in range(3):
             cam.light[i] = float(light[i])
         cam.near, cam.far = float(camera.near), float(camera.far)
+        cam.camtype = {"perspective": 0, "pano": 1}[getattr(camera, "camtype", "perspective")]
         dev = f"cuda:{self.device}"
         if rect is not None:
             x0, y0, w, hgt = (int(v) for v in rect)

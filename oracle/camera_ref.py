@@ -15,7 +15,7 @@ def get_pixtocam(focal, width, height):
     return np.linalg.inv(camtopix)
 
 
-def pixels_to_rays(pix_x_int, pix_y_int, pixtocam, camtoworld, dtype=np.float32):
+def pixels_to_rays(pix_x_int, pix_y_int, pixtocam, camtoworld, dtype=np.float32, camtype="perspective"):
     pix_x_int = np.asarray(pix_x_int)
     pix_y_int = np.asarray(pix_y_int)
     pixtocam = np.asarray(pixtocam, dtype)
@@ -29,6 +29,10 @@ def pixels_to_rays(pix_x_int, pix_y_int, pixtocam, camtoworld, dtype=np.float32)
     stacked = np.stack([pix_to_dir(px, py), pix_to_dir(px + 1, py), pix_to_dir(px, py + 1)], axis=0)
     mat_vec_mul = lambda A, b: np.matmul(A, b[..., None])[..., 0]
     cam_dirs = mat_vec_mul(pixtocam, stacked)
+    if camtype == "pano":
+        # ProjectionType.PANORAMIC (:1013-1024)
+        theta, phi = cam_dirs[..., 0], cam_dirs[..., 1]
+        cam_dirs = np.stack([-np.sin(phi) * np.sin(theta), -np.cos(phi), -np.sin(phi) * np.cos(theta)], axis=-1).astype(dtype)
     cam_dirs = np.matmul(cam_dirs, np.diag(np.array([1.0, -1.0, -1.0], dtype)))      # OpenCV -> OpenGL
     imageplane = cam_dirs[0, ..., :2]
     dirs = mat_vec_mul(camtoworld[..., :3, :3], cam_dirs)
@@ -44,12 +48,21 @@ def pixels_to_rays(pix_x_int, pix_y_int, pixtocam, camtoworld, dtype=np.float32)
                 look=look, up=up)
 
 
-def cast_ray_batch(pixtocam, camtoworld, light, pix_x_int, pix_y_int, near, far, dtype=np.float32):
+def cast_ray_batch(pixtocam, camtoworld, light, pix_x_int, pix_y_int, near, far, dtype=np.float32, camtype="perspective"):
     """cast_ray_batch for one camera: rays + lights = lights[cam_idx], cam_origins = origins, near / far from Pixels."""
-    r = pixels_to_rays(pix_x_int, pix_y_int, pixtocam, camtoworld, dtype)
+    r = pixels_to_rays(pix_x_int, pix_y_int, pixtocam, camtoworld, dtype, camtype)
     shape = r["directions"].shape
     r["lights"] = np.broadcast_to(np.asarray(light, dtype), shape)
     r["cam_origins"] = r["origins"]
     r["near"] = np.full(shape[:-1] + (1,), near, dtype)
     r["far"] = np.full(shape[:-1] + (1,), far, dtype)
     return r
+
+
+def cast_spherical_rays(camtoworld, height, width, near, far, light=None, dtype=np.float32):
+    """camera_utils.cast_spherical_rays (:1415-1443) -> cast_general_rays with ProjectionType.PANORAMIC."""
+    pixtocam = np.diag(np.array([2.0 * np.pi / width, np.pi / height, 1.0]))
+    py, px = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
+    camtoworld = np.asarray(camtoworld)[:3, :4]
+    light = camtoworld[:3, 3] if light is None else light
+    return cast_ray_batch(pixtocam, camtoworld, light, px, py, near, far, dtype, camtype="pano")

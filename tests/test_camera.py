@@ -93,3 +93,39 @@ def test_render_camera_equals_render_of_host_rays():
     torch.cuda.synchronize()
     assert np.abs(img["rgb"].reshape(-1, 3) - out["rgb"].cpu().numpy()).max() <= 1e-4      # ray fields agree to 2e-6
     assert np.abs(img["acc"].reshape(-1) - out["acc"].cpu().numpy()).max() <= 1e-4
+
+
+def test_spherical_rays_known_answers():
+    """cast_spherical_rays (camera_utils.py:1415-1443, :1013-1024): a full panorama of unit directions."""
+    H, W = 6, 12
+    c2w = np.concatenate([np.eye(3), [[1.0], [2.0], [3.0]]], axis=1)
+    r = camera_ref.cast_spherical_rays(c2w, H, W, 0.1, 5.0, dtype=np.float64)
+    d = r["directions"]
+    assert d.shape == (H, W, 3) and np.allclose(np.linalg.norm(d, axis=-1), 1.0)
+    # pixel (x, y): theta = 2 pi (x + 0.5) / W, phi = pi (y + 0.5) / H; camera (OpenCV) direction
+    # (-sin phi sin theta, -cos phi, -sin phi cos theta), then diag(1, -1, -1) and the identity rotation
+    x, y = 4, 1
+    th, ph = 2 * np.pi * (x + 0.5) / W, np.pi * (y + 0.5) / H
+    assert np.allclose(d[y, x], [-np.sin(ph) * np.sin(th), np.cos(ph), np.sin(ph) * np.cos(th)])
+    # rows run from the +y pole to the -y pole, columns once around it; opposite columns are mirrored in x and z
+    assert d[0, :, 1].min() > 0.9 and d[-1, :, 1].max() < -0.9
+    assert np.allclose(d[:, :W // 2, 0], -d[:, W // 2:, 0]) and np.allclose(d[:, :W // 2, 2], -d[:, W // 2:, 2])
+    assert np.allclose(r["origins"], [1.0, 2.0, 3.0]) and np.allclose(r["lights"], [1.0, 2.0, 3.0])
+    assert np.all(r["near"] == 0.1) and np.all(r["far"] == 5.0)
+
+
+@pytest.mark.gpu
+def test_spherical_rays_on_device_match_oracle():
+    from nrc_amd import rc_ext
+    rc = rc_ext.RadianceCache(nrc_amd.hotdog_config(), 0)
+    H, W = 33, 70
+    c2w = _lookat([0.3, -0.2, 0.4])
+    ref = camera_ref.cast_spherical_rays(c2w, H, W, 0.05, 2.0)
+    got = nrc_amd.cast_spherical_rays(rc, c2w, H, W, 0.05, 2.0)
+    torch.cuda.synchronize()
+    for k in ("origins", "directions", "viewdirs", "radii", "imageplane", "lights", "near", "far"):
+        g = getattr(got, k).cpu().numpy()
+        assert g.shape == ref[k].shape, k
+        assert np.abs(g - ref[k]).max() <= 4e-6 * max(1.0, np.abs(ref[k]).max()), k
+    with pytest.raises(KeyError):
+        rc.cast_rays(nrc_amd.Camera(np.eye(3), c2w, camtype="fisheye"), rect=(0, 0, 2, 2))
