@@ -182,3 +182,33 @@ def test_allreduce_grads_two_ranks_gloo(tmp_path):
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+@pytest.mark.gpu
+def test_gradient_descent_on_the_density_field_reduces_the_loss():
+    """A few plain SGD steps driven by rc_density_backward: fit level 2's density at fixed points to a target field.
+    Exercises the whole loop a trainer would run -- forward value, upstream gradient, gradient buffer by tensor name,
+    parameter update on the device, rc_load_weights of the changed tensors (device pointers), repacked weight stream."""
+    rc = common.make_rc()
+    level = 2
+    pts = torch.from_numpy(_points(4096, seed=21, spread=0.5)).cuda()
+    layout, total = rc.density_grad_layout(level)
+    params = {k: torch.from_numpy(v).cuda() for k, v in common.weights_np().items() if any(k == name for name, _, _ in layout)}
+    assert set(params) == {name for name, _, _ in layout}
+    zeros = torch.zeros(pts.shape[0], device="cuda")
+    _, dens0 = rc.density_backward(level, pts, zeros)
+    target = 0.5 * dens0 + 0.05                         # a reachable field
+    flat = torch.zeros(total, dtype=torch.float32, device="cuda")
+    losses = []
+    lr = {"grid": 5.0, "mlp": 5e-2}
+    for step in range(16):
+        _, dens = rc.density_backward(level, pts, zeros)           # forward value only (zero upstream: no gradient)
+        diff = dens - target
+        losses.append(float((diff * diff).mean()))
+        flat.zero_()
+        g, _, _ = nrc_amd.train.density_grads(rc, level, pts, 2.0 * diff / diff.numel(), None, flat)
+        for name, grad in g.items():
+            params[name] -= (lr["grid"] if "density_grid" in name else lr["mlp"]) * grad
+        rc.load_weights(params)
+    assert losses[-1] < 0.6 * losses[0], losses
+    assert all(b <= a * 1.02 for a, b in zip(losses, losses[1:])), losses
