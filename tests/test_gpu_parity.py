@@ -742,3 +742,46 @@ def test_transient_render_image_keys_and_shapes():
     # chunk 0 (16 rays) of the image == the same 16 rays rendered directly
     direct = m.rc.render_transient({k: np.asarray(v)[:16] for k, v in flat.hot_fields().items()}, None, outputs=["rgb"])
     assert np.array_equal(img["rgb"].reshape(H * W, 700, 3)[:16], direct["rgb"].cpu().numpy())
+
+
+def test_repeated_launches_are_bitwise_stable(rc):
+    """Race check of the weight-ring / LDS protocols: the same batch rendered many times (eager launches, two streams in
+    flight) must come out bit for bit the same -- nothing in the cache pass depends on arrival order."""
+    n = 1024
+    rays = nrc_amd.synthetic_rays(n, seed=77)
+    f = {k: torch.from_numpy(np.asarray(v)).cuda().contiguous() for k, v in rays.hot_fields().items()}
+    rnd = {"jitter": [torch.from_numpy(j).cuda() for j in common.jitters(n, seed=5)]}
+    rc.set_graph_mode(0)
+    try:
+        first = {k: v.clone() for k, v in rc.render_rays(f, rnd).items()}
+        side = torch.cuda.Stream()
+        for it in range(150):
+            if it % 2:
+                with torch.cuda.stream(side):
+                    out = rc.render_rays(f, rnd)
+                side.synchronize()
+            else:
+                out = rc.render_rays(f, rnd)
+                torch.cuda.synchronize()
+            for k, v in out.items():
+                assert torch.equal(v, first[k]), (it, k)
+    finally:
+        rc.set_graph_mode(1)
+
+
+def test_transient_repeated_launches_are_stable():
+    """k_transient_bins adds into LDS histograms with plain read-add-writes; the lane / half-wave ownership makes that
+    deterministic: repeated launches agree bit for bit."""
+    from nrc_amd import rc_ext
+    cfg = nrc_amd.cornell_transient_config()
+    h = rc_ext.RadianceCache(cfg, 0)
+    h.load_weights(common.weights_transient_np())
+    rays = nrc_amd.synthetic_transient_rays(256)
+    f = {k: torch.from_numpy(np.asarray(v)).cuda().contiguous() for k, v in rays.hot_fields().items()}
+    keys = ["rgb", "integrated_rgb", "transient_indirect_viz", "transient_direct_viz"]
+    first = {k: v.clone() for k, v in h.render_transient(f, None, outputs=keys).items()}
+    for it in range(40):
+        out = h.render_transient(f, None, outputs=keys)
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(out[k], first[k]), (it, k)
