@@ -387,6 +387,15 @@ int rc_density_grad_layout(rc_handle* h, int32_t level, rc_grad_segment* segs, i
 int rc_density_backward(rc_handle* h, int32_t level, const float* points, int64_t n, const float* d_density,
                         const float* d_feature, float* grads, float* density_out, void* stream);
 
+/* Transpose of rc_hashgrid_lookup for any grid of the handle (0-2 proposal density grids, 3 appearance, 4 material,
+ * 5 light): d_features [n, L*F] (the layout rc_hashgrid_lookup writes) is scattered into `grads`, a device buffer of
+ * `total` floats holding the grid's tables in level order, each laid out like the loaded tensor
+ * (rc_hashgrid_grad_layout; names = the reference's parameter paths).  Accumulates; hardware float atomics.
+ * What jax's autodiff emits for HashEncoding.__call__ (internal/grid_utils.py:808-905) inside train_step. */
+int rc_hashgrid_grad_layout(rc_handle* h, int32_t grid_id, rc_grad_segment* segs, int32_t capacity, int32_t* count, int64_t* total);
+int rc_hashgrid_backward(rc_handle* h, int32_t grid_id, const float* points, int64_t n, const float* d_features, float* grads,
+                         int32_t apply_contraction, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

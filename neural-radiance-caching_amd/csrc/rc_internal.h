@@ -337,8 +337,9 @@ struct RcGridScatterArgs {
   float* gtable[RC_MAX_GRID_LEVELS];   // gradient tables, same layout as the forward tables
   const float* points;        // world-space [n,3]
   int64_t n; int64_t ld;
-  const float* dfeat;         // feature-major [L*F][ld]
+  const float* dfeat;         // feature-major [L*F][ld], or point-major [n][L*F] (point_major != 0)
   float contract_radius;
+  int32_t point_major;
   int32_t level0;             // first level of this launch (blockIdx.y = level - level0)
   uint32_t lds_levels;        // bit l: level l is summed through LDS by k_grid_scatter_small
 };

@@ -288,7 +288,8 @@ __global__ __launch_bounds__(256) void k_grid_scatter(RcGridScatterArgs a) {
   const RcGridLevel L = a.grid.lvl[l];
   float* __restrict__ gt = a.gtable[l];
   const int f = F == 4 ? sub : 0;
-  const float df = a.dfeat[(int64_t)(l * F + f) * a.ld + p] * a.grid.precondition;
+  const int LF = a.grid.num_levels * F;
+  const float df = (a.point_major ? a.dfeat[p * LF + l * F + f] : a.dfeat[(int64_t)(l * F + f) * a.ld + p]) * a.grid.precondition;
   const float N = (float)L.size;
   const float cx = unit_box(a.grid.bbox, x) * N, cy = unit_box(a.grid.bbox, y) * N, cz = unit_box(a.grid.bbox, z) * N;
   float cw[3];
@@ -344,7 +345,8 @@ __global__ __launch_bounds__(256) void k_grid_scatter_small(RcGridScatterArgs a,
     if (a.contract_radius > 0.0f) contract3(x, y, z, a.contract_radius);
     float df[F];
 #pragma unroll
-    for (int f = 0; f < F; ++f) df[f] = a.dfeat[(int64_t)(l * F + f) * a.ld + p] * a.grid.precondition;
+    for (int f = 0; f < F; ++f)
+      df[f] = (a.point_major ? a.dfeat[p * (a.grid.num_levels * F) + l * F + f] : a.dfeat[(int64_t)(l * F + f) * a.ld + p]) * a.grid.precondition;
     const float loc[3] = {(unit_box(a.grid.bbox, z) * N - 0.5f) + 1.0f, (unit_box(a.grid.bbox, y) * N - 0.5f) + 1.0f,
                           (unit_box(a.grid.bbox, x) * N - 0.5f) + 1.0f};
     float cw[3], fw[3];

@@ -147,6 +147,7 @@ EXPORTS = (
     "rc_hashgrid_lookup", "rc_sample_intervals", "rc_workspace_ptr", "rc_set_profiling", "rc_stage_count",
     "rc_stage_name", "rc_stage_times_ms", "rc_set_graph_mode", "rc_set_fused", "rc_render_material", "rc_set_transient", "rc_render_transient", "rc_cast_rays",
     "rc_prng_fill", "rc_density_grad_size", "rc_density_grad_layout", "rc_density_backward",
+    "rc_hashgrid_grad_layout", "rc_hashgrid_backward",
 )
 
 _LIB = None
@@ -213,6 +214,10 @@ def load_library():
     lib.rc_density_backward.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
     lib.rc_density_backward.restype = C.c_int
+    lib.rc_hashgrid_grad_layout.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    lib.rc_hashgrid_grad_layout.restype = C.c_int
+    lib.rc_hashgrid_backward.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.rc_hashgrid_backward.restype = C.c_int
     lib.rc_stage_count.restype = C.c_int
     lib.rc_stage_name.argtypes = [C.c_int32]
     lib.rc_stage_name.restype = C.c_char_p
@@ -436,6 +441,35 @@ class RadianceCache:
             self._check(total)
         return out, total
 
+    def hashgrid_grad_layout(self, grid_id: int):
+        """rc_hashgrid_grad_layout: [(tensor name, offset, shape)] of the table-gradient buffer of a grid, and its size."""
+        cnt, total = C.c_int32(), C.c_int64()
+        self._check(self.lib.rc_hashgrid_grad_layout(self._h, grid_id, None, 0, C.byref(cnt), C.byref(total)))
+        segs = (rc_grad_segment * cnt.value)()
+        self._check(self.lib.rc_hashgrid_grad_layout(self._h, grid_id, segs, cnt.value, C.byref(cnt), C.byref(total)))
+        return [(s.name.decode(), int(s.offset), tuple(int(v) for v in s.shape[: s.ndim])) for s in segs], int(total.value)
+
+    def hashgrid_backward(self, grid_id: int, points, d_features, grads=None, apply_contraction: bool = True):
+        """rc_hashgrid_backward: scatter d L / d features [n, L*F] (the layout hashgrid_lookup returns) into the tables'
+        gradient buffer (flat float32 cuda tensor of hashgrid_grad_layout(grid_id)[1] elements; accumulated into when given)."""
+        torch = self._torch
+        pts = self._dev(points).reshape(-1, 3).contiguous()
+        n = pts.shape[0]
+        df = self._dev(d_features).reshape(n, -1).contiguous()
+        _, total = self.hashgrid_grad_layout(grid_id)
+        if grads is None:
+            grads = torch.zeros(total, dtype=torch.float32, device=f"cuda:{self.device}")
+        elif grads.numel() != total or grads.dtype != torch.float32 or not grads.is_cuda or not grads.is_contiguous():
+            raise ValueError(f"grads must be a contiguous float32 cuda tensor of {total} elements")
+        g = self.cfg_grid(grid_id)
+        if df.shape[1] != g.out_dim:
+            raise ValueError(f"d_features must have {g.out_dim} columns")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.rc_hashgrid_backward(self._h, grid_id, pts.data_ptr(), n, df.data_ptr(), grads.data_ptr(),
+                                                  1 if apply_contraction else 0, stream))
+        self._keep = [pts, df]
+        return grads
+
     def density_backward(self, level: int, points, d_density, d_feature=None, grads=None):
         """rc_density_backward: gradients of L w.r.t. the hash-grid tables and the density MLP of proposal level `level`
         given d L / d density [n] (and d L / d feature [n, 64]) at the world-space sample means `points` [n, 3].
@@ -610,9 +644,13 @@ class RadianceCache:
         return cres, mres
 
     # -- single operators ---------------------------------------------------------------------
+    def cfg_grid(self, grid_id: int):
+        """GridConfig of grid 0-2 (proposal density grids), 3 (appearance), 4 (material), 5 (light)."""
+        return (list(self.cfg.proposal_grids) + [self.cfg.appearance_grid, self.cfg.material_grid, self.cfg.light_grid])[grid_id]
+
     def hashgrid_lookup(self, grid_id: int, points, apply_contraction: bool = True):
         torch = self._torch
-        g = (list(self.cfg.proposal_grids) + [self.cfg.appearance_grid, self.cfg.material_grid, self.cfg.light_grid])[grid_id]
+        g = self.cfg_grid(grid_id)
         p = self._dev(points).reshape(-1, 3)
         out = torch.empty((p.shape[0], g.out_dim), dtype=torch.float32, device=p.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream

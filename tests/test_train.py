@@ -212,3 +212,42 @@ def test_gradient_descent_on_the_density_field_reduces_the_loss():
         rc.load_weights(params)
     assert losses[-1] < 0.6 * losses[0], losses
     assert all(b <= a * 1.02 for a, b in zip(losses, losses[1:])), losses
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid_id", [1, 3])
+def test_hashgrid_backward_is_the_transpose_of_the_lookup(grid_id):
+    """rc_hashgrid_backward against autograd through the oracle's hash encoding, and <lookup(T), d> == <T, backward(d)>."""
+    from oracle import hashgrid_ref, mathx
+    from oracle.cache_ref import P
+    rc = common.make_rc()
+    n = 777
+    pts = _points(n, seed=31)
+    g = rc.cfg_grid(grid_id)
+    rng = np.random.Generator(np.random.PCG64(32))
+    d = rng.normal(size=(n, g.out_dim)).astype(np.float32)
+    layout, total = rc.hashgrid_grad_layout(grid_id)
+    flat = rc.hashgrid_backward(grid_id, pts, d)
+    # oracle: autograd of sum(d * encoding) w.r.t. the tables
+    w = common.weights_torch(dtype=torch.float64)
+    prefix = layout[0][0].rsplit("/", 1)[0]
+    names = [name for name, _, _ in layout]
+    ww = dict(w)
+    for k in names:
+        ww[k] = w[k].detach().clone().requires_grad_(True)
+    x = hashgrid_ref.hash_encoding(ww, prefix, g, mathx.contract_radius(torch.from_numpy(pts).double(), CFG.contract_radius))
+    grads = torch.autograd.grad((torch.from_numpy(d).double() * x).sum(), [ww[k] for k in names])
+    got = flat.cpu().numpy().astype(np.float64)
+    for (name, off, shape), gr in zip(layout, grads):
+        ref = gr.numpy().reshape(-1)
+        a = got[off: off + ref.size]
+        scale = max(1e-12, float(np.abs(ref).max()))
+        # float32 trilinear weights at grid sizes up to 2048: a coordinate ulp is 1e-4 of a cell (2.2e-4 measured at 2048)
+        assert float(np.abs(a - ref).max()) <= 5e-4 * scale + 1e-7, (name, float(np.abs(a - ref).max()), scale)
+    # adjoint identity with the device's own forward lookup
+    tables = torch.cat([torch.from_numpy(common.weights_np()[name]).reshape(-1) for name in names]).cuda()
+    fwd = rc.hashgrid_lookup(grid_id, pts)
+    lhs = float((fwd.double() * torch.from_numpy(d).cuda().double()).sum())
+    rhs = float((tables.double() * flat.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (lhs, rhs)
+    assert P in names[0]
