@@ -486,6 +486,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
 #pragma unroll
   for (int r = 0; r < 16; ++r) cval[r] = 0.0f;
   float* hist_h = hist_i + h * kHistPad;
+  const int nb_addr = 4 * (fl < 3 ? lane + 29 : lane - 3);     // ds_bpermute byte address of the neighbour entry's lane
 #ifdef RC_STAMPS
   unsigned long long st_mfma = 0, st_epi = 0;
   const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
@@ -548,17 +549,21 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
         sdu[r] += diff; ssu[r] += spec;
         cd += w * diff; cs += w * spec;
         const float val = w * (diff + spec);
-        const float below = __shfl_up(val, 3, 64);                   // entry f - 3 of this tile (fl >= 3)
-        const float before = __shfl(cval[r], (lane + 29) & 63, 64);  // entry f - 3 of the tile before (fl < 3)
-        const float nb = fl < 3 ? before : below;
+        // entry f - 3: three lanes down in this tile (fl >= 3), or lanes 29-31 of the tile before (fl < 3) -- one
+        // bpermute: the lanes that serve the second case (fl >= 29) are never a source of the first
+        const float nb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(
+            nb_addr, __builtin_bit_cast(int, fl >= 29 ? cval[r] : val)));
         cval[r] = val;
-        // the weights are those the target bin computes (coordinate y0 - d, floor, linear): wa for entry b, wb for b - 1
+        // The weights are those the target bin computes (coordinate t = y0 - d, i0 = floor(t), fw = t - i0; weight
+        // 1 - fw to source bin i0 and fw to i0 + 1): wa for source b, wb for source b - 1.  t lies in [b - 1, b], so
+        // i0 is b - 1 (wa = fw, wb = 1 - fw) or, when d is integral or t rounds up to b, b (wa = 1 - fw, wb = 0);
+        // the reference's other terms are exact zeros.
         const float t = (float)y0 - dmove;
         const float i0 = floorf(t);
         const float fw = t - i0;
-        const int ii = (int)i0;
-        const float wa = (ii == b ? 1.0f - fw : 0.0f) + (ii + 1 == b ? fw : 0.0f);
-        const float wb = (ii == b - 1 ? 1.0f - fw : 0.0f) + (ii + 1 == b - 1 ? fw : 0.0f);
+        const bool at_b = (int)i0 == b;
+        const float wa = at_b ? 1.0f - fw : fw;
+        const float wb = at_b ? 0.0f : 1.0f - fw;
 #if defined(RC_ABL) && RC_ABL == 2
         cd += yok ? val * wa + nb * wb : 0.0f;      // ablation: no histogram update
 #else
