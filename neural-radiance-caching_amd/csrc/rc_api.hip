@@ -664,6 +664,11 @@ int ensure_workspace(rc_handle* h, int64_t n) {
   if ((rc = ws_alloc(h, "inds", n))) return rc;
   if ((rc = ws_alloc(h, "src_idx", n))) return rc;
   if ((rc = ws_alloc(h, "filt_weight", n))) return rc;
+  // lean resampling pass: last-level features / hidden vector / predicted normals of the picked samples only
+  if ((rc = ws_alloc(h, "feat_sel", 32 * n))) return rc;
+  if ((rc = ws_alloc(h, "hbuf_sel", ((n + 31) / 32) * 32 * 64))) return rc;
+  if ((rc = ws_alloc(h, "normals_sel", 3 * n))) return rc;
+  if ((rc = ws_alloc(h, "density_sel", n))) return rc;
   if (h->transient && h->ws_prefix.empty()) {
     const int64_t tiles = (np + 31) / 32;
     if ((rc = ws_alloc(h, "t_irr", tiles * 32 * 64))) return rc;
@@ -965,6 +970,9 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
   const rc_randoms* rnd = A.have_rnd ? &A.rnd : nullptr;
   const bool secondary = (A.mask & RC_PASS_SECONDARY) != 0;
   const bool resample = secondary || (A.mask & RC_PASS_RESAMPLE);
+  // lean: no per-sample consumer of the last level's hidden feature / predicted normals besides the shader
+  const bool lean = resample && !A.tout && !A.weights_only && !A.force_grad && !A.out.ptr[RC_OUT_NORMALS_PRED] &&
+                    !A.out.ptr[RC_OUT_NORMALS];
   const int slot = A.slot;
   if (A.fused) {
     RcFusedLaunch F{};
@@ -1026,8 +1034,10 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     da.density_bias = c.density_bias; da.contract_radius = c.contract_radius; da.bbox = h->grids[l].cfg.bbox;
     da.last = (l == NL - 1) ? 1 : 0;
     da.density = W(h, "density" + L);
-    da.hbuf = da.last ? W(h, "hbuf") : nullptr;
-    da.normals_pred = da.last ? W(h, "normals_pred") : nullptr;
+    // lean resampling pass: the hidden feature / predicted normals are only needed at the ONE sample per ray picked
+    // below, so they are not written for all of them here (256 + 12 bytes per sample) but recomputed for the picks
+    da.hbuf = (da.last && !lean) ? W(h, "hbuf") : nullptr;
+    da.normals_pred = (da.last && !lean) ? W(h, "normals_pred") : nullptr;
     da.jac = want_grad ? W(h, "jac") : nullptr;
     da.normals_grad = want_grad ? W(h, "normals_grad") : nullptr;
     stage_mark(h, slot, ST_MLP0 + 3 * l, st);
@@ -1062,6 +1072,20 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     src = (const int32_t*)W(h, "src_idx");
   }
   const int64_t nsh = resample ? n : np2;
+  if (lean) {
+    // density MLP of the last level once more, on the picked samples only (same kernel, same per-point arithmetic:
+    // bitwise the values the full pass would have stored), compact outputs
+    const int l2 = NL - 1;
+    const int K2 = h->grids[l2].dev.num_levels * h->grids[l2].dev.num_features;
+    rc_launch_hashgrid_src(h->grids[l2].dev, W(h, "means" + LL), 1, src, np2, n, W(h, "feat_sel"), 1, n, c.contract_radius,
+                           nullptr, st);
+    RcDensityMlpArgs ds{};
+    ds.feat = W(h, "feat_sel"); ds.n = n; ds.ld = n; ds.K = K2; ds.wstream = h->packs["dens_" + LL].p;
+    ds.means = W(h, "means" + LL); ds.src = src; ds.n_src = np2;
+    ds.density_bias = c.density_bias; ds.contract_radius = c.contract_radius; ds.bbox = h->grids[l2].cfg.bbox;
+    ds.last = 1; ds.density = W(h, "density_sel"); ds.hbuf = W(h, "hbuf_sel"); ds.normals_pred = W(h, "normals_sel");
+    rc_launch_density_mlp(ds, st);
+  }
   stage_mark(h, slot, ST_GRID_APP, st);
   rc_launch_hashgrid_src(h->grids[3].dev, W(h, "means" + LL), 1, src, np2, nsh, W(h, "app"), 1, nsh,
                          c.contract_radius, nullptr, st);
@@ -1072,8 +1096,9 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
   stage_mark(h, slot, ST_SHADER, st);
   {
     RcShaderArgs s{};
-    s.n = nsh; s.n_src = np2; s.src = src; s.samples_per_ray = resample ? 1 : S2;
-    s.hbuf = W(h, "hbuf"); s.app = W(h, "app"); s.normals_pred = W(h, "normals_pred"); s.viewdirs = rays->viewdirs;
+    s.n = nsh; s.n_src = lean ? n : np2; s.src = lean ? nullptr : src; s.samples_per_ray = resample ? 1 : S2;
+    s.hbuf = W(h, lean ? "hbuf_sel" : "hbuf"); s.app = W(h, "app");
+    s.normals_pred = W(h, lean ? "normals_sel" : "normals_pred"); s.viewdirs = rays->viewdirs;
     s.wstream = h->packs["shader"].p; s.ide_coef = h->ide_table.p;
     s.roughness_bias = c.roughness_bias; s.irradiance_bias = c.irradiance_bias; s.ambient_bias = c.ambient_irradiance_bias;
     s.rgb_max = c.rgb_max; s.slf_ambient_bias = c.slf_ambient_bias;
@@ -1086,7 +1111,7 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     RcCompositeArgs ca{};
     ca.directions = rays->directions; ca.origins = rays->origins; ca.lights = rays->lights; ca.n_rays = n; ca.S = S2;
     ca.tdist = W(h, "tdist" + LL); ca.density = W(h, "density" + LL); ca.means = W(h, "means" + LL);
-    ca.normals_pred = W(h, "normals_pred");
+    ca.normals_pred = lean ? nullptr : W(h, "normals_pred");
     ca.normals_grad = A.out.ptr[RC_OUT_NORMALS] ? W(h, "normals_grad") : nullptr;
     ca.shade = W(h, "shade"); ca.Sf = resample ? 1 : S2;
     ca.inds = resample ? (const int32_t*)W(h, "inds") : nullptr;

@@ -117,7 +117,8 @@ struct RcDensityMlpArgs {
   int64_t n; int64_t ld;
   int32_t K;                  // 6, 7 or 32
   const float* wstream;       // packed MFMA fragment stream [d0 | d1 | out]
-  const float* means;         // SoA [3][n] (validity mask)
+  const float* means;         // SoA [3][n] (validity mask); with `src`: SoA [3][n_src], point p reads column src[p]
+  const int32_t* src; int64_t n_src;
   float density_bias, contract_radius, bbox;
   int32_t last;               // 1: also write hidden feature + predicted normals
   float* density;             // [n]

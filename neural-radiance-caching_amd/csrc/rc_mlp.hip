@@ -96,8 +96,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
   float cx = 0.0f, cy = 0.0f, cz = 0.0f;   // contracted position
   float zx = 0.0f, zy = 0.0f, zz = 0.0f;   // x / radius
   if (valid) {
-    zx = a.means[p] / a.contract_radius; zy = a.means[a.n + p] / a.contract_radius; zz = a.means[2 * a.n + p] / a.contract_radius;
-    cx = a.means[p]; cy = a.means[a.n + p]; cz = a.means[2 * a.n + p];
+    const int64_t q = a.src ? (int64_t)a.src[p] : p, ms = a.src ? a.n_src : a.n;
+    zx = a.means[q] / a.contract_radius; zy = a.means[ms + q] / a.contract_radius; zz = a.means[2 * ms + q] / a.contract_radius;
+    cx = a.means[q]; cy = a.means[ms + q]; cz = a.means[2 * ms + q];
     contract3(cx, cy, cz, a.contract_radius);
   }
   if (h == 0 && valid) {

@@ -785,3 +785,28 @@ def test_transient_repeated_launches_are_stable():
         torch.cuda.synchronize()
         for k in keys:
             assert torch.equal(out[k], first[k]), (it, k)
+
+
+def test_lean_resampling_pass_equals_the_full_one(rc):
+    """A resampling pass that is not asked for normals recomputes the last level's hidden feature / predicted normals
+    for the ONE picked sample per ray instead of storing them for all 32: same per-point arithmetic, same bits."""
+    from nrc_amd import rc_ext
+    n = 777
+    rays, rnd = common.secondary_case(n, seed=13)
+    mask = rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_SECONDARY
+    full = rc.render_rays(rays, rnd, mask)                                   # every output incl. normals: full pass
+    keys = [k for k in full if "normals" not in k]
+    lean = rc.render_rays(rays, rnd, mask, outputs=keys)                     # lean pass
+    torch.cuda.synchronize()
+    for k in keys:
+        assert torch.equal(lean[k], full[k]), k
+    # primary rays with resample=True
+    g = np.random.Generator(np.random.PCG64(3)).gumbel(size=(n, 32)).astype(np.float32)
+    prays = nrc_amd.synthetic_rays(n, seed=14).hot_fields()
+    prnd = {"jitter": common.jitters(n, seed=2), "gumbel": g}
+    pmask = rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_RESAMPLE
+    pfull = rc.render_rays(prays, prnd, pmask)
+    plean = rc.render_rays(prays, prnd, pmask, outputs=["rgb", "acc", "diffuse_rgb", "specular_rgb"])
+    torch.cuda.synchronize()
+    for k in plean:
+        assert torch.equal(plean[k], pfull[k]), k
