@@ -29,11 +29,6 @@ constexpr int kRingFloats = 2 * kChunk * 64;     // two chunks
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
-// Slots of a kernel's ring, by the fragment count of its stream (every kernel has its own NF): 2 = chunk c + 1 in flight
-// while chunk c is consumed; a kernel that can afford a third 16 KiB slot specialises this to 3 and keeps TWO chunks in
-// flight, so that the wait at a chunk seam finds its data already there.
-template <int NF> struct WsRing { static constexpr int kSlots = 2; };
-
 struct WStream {
   const float* g;    // packed fragment stream (padded to a whole number of chunks)
   float* ring;       // LDS ring [2 * kChunk][64]
@@ -52,7 +47,7 @@ __device__ __forceinline__ void ws_issue(const WStream& w, int c) {
     const int frag0 = c * CH + 4 * i;
     if (frag0 < NF) {
       const float* src = w.g + (size_t)frag0 * 64 + w.lane * 4;
-      float* dst = w.ring + ((c % WsRing<NF>::kSlots) * CH + 4 * i) * 64;
+      float* dst = w.ring + ((c & 1) * CH + 4 * i) * 64;
       __builtin_amdgcn_global_load_lds((const void*)src, (lds_void_ptr)dst, 16, 0, 0);
     }
   }
@@ -61,35 +56,24 @@ __device__ __forceinline__ void ws_issue(const WStream& w, int c) {
 template <int NF, int W = kWaves, int CH = kChunk>
 __device__ __forceinline__ void ws_begin(const WStream& w) {
   ws_issue<NF, W, CH>(w, 0);
-  if (WsRing<NF>::kSlots == 3 && CH < NF) ws_issue<NF, W, CH>(w, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if ((WsRing<NF>::kSlots - 1) * CH < NF) ws_issue<NF, W, CH>(w, WsRing<NF>::kSlots - 1);
+  if (CH < NF) ws_issue<NF, W, CH>(w, 1);
 }
 
 // Entering chunk c: it has landed (issued one chunk ago), everybody is done with chunk c-1.
 template <int NF, int W = kWaves, int CH = kChunk>
 __device__ __forceinline__ void ws_advance(const WStream& w, int c) {
-  if (WsRing<NF>::kSlots == 3) {
-    // chunk c + 1 (issued one seam ago: CH / 4 / W loads of this wave, the youngest ones) may stay in flight; when it
-    // is not a whole chunk the waves issued different numbers of loads for it: wait for everything then
-    static_assert(WsRing<NF>::kSlots != 3 || CH / 4 / W == 4, "the immediate below");
-    if ((c + 2) * CH <= NF) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if ((c + 2) * CH < NF) ws_issue<NF, W, CH>(w, c + 2);
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if ((c + 1) * CH < NF) ws_issue<NF, W, CH>(w, c + 1);
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if ((c + 1) * CH < NF) ws_issue<NF, W, CH>(w, c + 1);
 }
 
 // Read fragment f of the stream as a per-lane value (used for lane-layout constant vectors).
 template <int NF, int W = kWaves, int CH = kChunk>
 __device__ __forceinline__ float ws_read(const WStream& w, int f) {
   if (f > 0 && f % CH == 0) ws_advance<NF, W, CH>(w, f / CH);
-  return w.ring[(f % (WsRing<NF>::kSlots * CH)) * 64 + w.lane];
+  return w.ring[(f % (2 * CH)) * 64 + w.lane];
 }
 
 // One pass over KS k-steps for NT output tiles; the layer's fragments are [FBASE, FBASE + KS*NT)
@@ -111,7 +95,7 @@ __device__ __forceinline__ void mlp_layer(const WStream& w, const float* act, f3
         for (int t = 0; t < NT; ++t) {
           const int f = FBASE + s * NT + t;            // compile-time after unrolling
           if (f > 0 && f % CH == 0) ws_advance<NF, W, CH>(w, f / CH);
-          a[buf][d][t] = w.ring[(f % (WsRing<NF>::kSlots * CH)) * 64 + w.lane];
+          a[buf][d][t] = w.ring[(f % (2 * CH)) * 64 + w.lane];
         }
       }
     }
@@ -158,7 +142,7 @@ __device__ __forceinline__ void mlp_layer_pt(const WStream& w, const float* act,
         for (int t = 0; t < NT; ++t) {
           const int f = FBASE + s * NT + t;
           if (f > 0 && f % kChunk == 0) ws_advance<NF, W>(w, f / kChunk);
-          a[buf][d][t] = w.ring[(f % (WsRing<NF>::kSlots * kChunk)) * 64 + w.lane];
+          a[buf][d][t] = w.ring[(f % (2 * kChunk)) * 64 + w.lane];
         }
       }
     }

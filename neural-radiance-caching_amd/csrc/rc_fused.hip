@@ -39,14 +39,6 @@ constexpr int F_L1 = F_L0 + DensFrags<4>::B1;        // K = 7: KS0 = 5
 constexpr int F_L2 = F_L1 + DensFrags<5>::B1;        // K = 32: KS0 = 17, with the 96 backward fragments
 constexpr int F_SH = F_L2 + DensFrags<17>::END;
 constexpr int NF = F_SH + ShaderFrags::COUNT;
-constexpr int kFusedRingFloats = 3 * kChunk * 64;    // three 16 KiB slots: two chunks of the stream in flight (WsRing below)
-
-}  // namespace
-
-// The fused kernel's 157 KiB of LDS leave room for a third ring slot: its ~40 chunk seams then find their data landed.
-template <> struct rcdev::WsRing<NF> { static constexpr int kSlots = 3; };
-
-namespace {
 
 // Density MLP of a proposal level on 64 samples (two point-tiles); returns the raw density of
 // sample `lane`.  K grid features of this lane's sample are in f[].
@@ -114,8 +106,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
   const bool ray_ok = ray < a.n;
   if (!ray_ok) ray = a.n - 1;                      // keep the wave in the workgroup's lockstep
   float* ring = lds_dyn;
-  float* act_wave = lds_dyn + kFusedRingFloats + wave * (kShActSteps * 64);
-  float* scr = lds_dyn + kFusedRingFloats + kWaves * (kShActSteps * 64) + wave * kScratch;
+  float* act_wave = lds_dyn + kRingFloats + wave * (kShActSteps * 64);
+  float* scr = lds_dyn + kRingFloats + kWaves * (kShActSteps * 64) + wave * kScratch;
   float* s_sd[2] = {scr, scr + 68};
   float* s_td = scr + 2 * 68; float* s_cw = scr + 3 * 68; float* s_c = scr + 4 * 68; float* s_v = scr + 5 * 68;
   float* s_out = scr + 6 * 68;
@@ -495,8 +487,7 @@ int rc_fused_stream_offsets(int* l0, int* l1, int* l2, int* sh) {
 void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream) {
   if (L.n <= 0) return;
   static std::atomic<uint64_t> prepared{0};
-  constexpr int lds = (kFusedRingFloats + kWaves * (kShActSteps * 64 + kScratch)) * (int)sizeof(float);
-  static_assert(lds <= 160 * 1024, "LDS of a CU");
+  const int lds = (kRingFloats + kWaves * (kShActSteps * 64 + kScratch)) * (int)sizeof(float);
   if (rc_first_use_on_device(prepared)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

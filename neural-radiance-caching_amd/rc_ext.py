@@ -154,7 +154,8 @@ _LIB = None
 
 
 def library_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "librc_hip.so")
+    # RC_HIP_LIBRARY: a diagnostic / A-B build of the same ABI (tools/README.md); the product is the in-tree library
+    return os.environ.get("RC_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librc_hip.so")
 
 
 def load_library():
