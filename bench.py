@@ -41,7 +41,7 @@ assert FUSED_FLOP_PER_RAY == 9703424
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
 # per-launch FETCH_SIZE + WRITE_SIZE (KiB) of the dominant kernel, profiles/r01_pmc_summary.txt
-PMC_KIB = {"fused": 114098.0 + 248.0, "shader": 8656.1 + 1920.0}
+PMC_KIB = {"fused": 114069.6 + 248.0, "shader": 8656.1 + 1920.0}
 
 
 def host_cpu_share(cap=16):
@@ -229,8 +229,9 @@ def main():
                     help="fused: one launch per batch (rc_set_fused 1, default); staged: one launch per stage")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent batches in flight: step i is enqueued on HIP stream i %% streams")
-    ap.add_argument("--profile-mode", type=int, default=2,
-                    help="events in the timed region: 0 none, 1 every stage, 2 dominant kernel only")
+    ap.add_argument("--profile-mode", type=int, default=3,
+                    help="HIP events in the timed region: 0 none, 1 every stage, 2 around the dominant kernel of every step, "
+                         "3 around the dominant kernel of every 8th step (default: the events of mode 2 cost 2 %% of a step)")
     args = ap.parse_args()
 
     import numpy as np
@@ -281,8 +282,9 @@ def main():
         with torch.cuda.stream(streams[i % nstr]):
             rc.render_rays(rays, None, out=outs[i % nstr])
 
-    # Timed region: two HIP events per step around the dominant kernel only (each event record costs
-    # a few us of GPU timeline, so the full per-stage profile is taken in a separate pass below).
+    # Timed region: two HIP events around the dominant kernel, on every 8th step by default (an event record costs
+    # ~1.3 us of stream time; the last 16 sampled launches, spread over the last 128 steps, are averaged).  The full
+    # per-stage profile is taken in a separate pass below.
     rc.set_profiling(args.profile_mode)
     for i in range(args.warmup):
         step(i)
@@ -337,7 +339,7 @@ def main():
         "config": {"workload": "hotdog cache render 1024 rays x (64,64,32) samples, cache-only passes, "
                                "synthetic rays + synthetic weights (configs[1])",
                    "rays_per_batch_per_gpu": RAYS_PER_BATCH, "parallelism": f"ray-sharded x{world}",
-                   "launch": "eager" if (args.profile_mode or args.graph_mode == 0) else "hipGraph",
+                   "launch": "eager" if (args.profile_mode or args.graph_mode == 0 or fused) else "hipGraph",
                    "batches_in_flight": nstr,
                    "kernel_plan": "fused: 1 launch per batch, 1 wavefront per ray" if fused else "staged: 13 launches per batch"},
         "roofline": {"kernel": "k_cache_fused" if fused else "k_cache_shader", "bound": "mfma", "achieved": achieved_tf,

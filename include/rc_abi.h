@@ -243,7 +243,8 @@ int rc_sample_intervals(rc_handle* h, const float* t, const float* logits, int64
 int rc_workspace_ptr(rc_handle* h, const char* name, void** ptr, int64_t* count);
 /* Per-stage device time (ms, hipEvents recorded on the launch stream), averaged over the calls
  * issued since profiling was last (re)enabled (ring of 16).  mode 0 off, 1 every stage,
- * 2 only the dominant kernel (cache shader; two events per call).  Profiled calls launch eagerly. */
+ * 2 only the dominant kernel (cache shader / the fused kernel; two events per call), 3 like 2 on every 8th call
+ * (the last 16 sampled calls span 128 calls; an event record costs ~1.3 us of stream time).  Profiled calls launch eagerly. */
 int rc_set_profiling(rc_handle* h, int32_t mode);
 /* Launch mode of rc_render_rays: 0 = eager kernel launches, 1 = capture a hipGraph the second time
  * an identical call (same sizes and pointers) is seen and replay it afterwards (default),
