@@ -233,6 +233,8 @@ def main():
                     help="HIP events in the timed region: 0 none, 1 every stage, 2 around the dominant kernel of every step, "
                          "3 around the dominant kernel of every 8th step (default: the events of mode 2 cost 2 %% of a step)")
     args = ap.parse_args()
+    if args.profile_mode == 3 and args.steps < 16:
+        args.profile_mode = 2            # too few steps to sample: events on every step
 
     import numpy as np
     import torch
