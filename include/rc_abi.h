@@ -248,7 +248,8 @@ int rc_workspace_ptr(rc_handle* h, const char* name, void** ptr, int64_t* count)
 int rc_set_profiling(rc_handle* h, int32_t mode);
 /* Launch mode of rc_render_rays: 0 = eager kernel launches, 1 = capture a hipGraph the second time
  * an identical call (same sizes and pointers) is seen and replay it afterwards (default),
- * 2 = capture on first sight. */
+ * 2 = capture on first sight.  Applies to the launch-per-stage plan; the one-launch fused plan (rc_set_fused) is always
+ * launched plainly (a one-node graph replays with a larger gap between launches than a plain launch). */
 int rc_set_graph_mode(rc_handle* h, int32_t mode);
 /* Kernel plan of the plain cache pass (pass_mask == RC_PASS_CACHE): 1 (default) = one fused launch per
  * batch, one wavefront per ray, all intermediates on chip (no workspace: rc_workspace_ptr then has
