@@ -107,6 +107,7 @@ struct rc_handle {
   // fused per-ray kernel for the plain cache pass (fused_mode: 0 never, 1 whenever eligible)
   int fused_mode = 1;
   bool fused_ok = false;
+  bool fused_front_ok = false;               // transient handles: the FRONT variant of the fused kernel is usable
   // hipGraph replay of the launch sequence (graph_mode: 0 off, 1 capture when a call repeats, 2 always)
   int graph_mode = 1;
   hipStream_t cap_stream = nullptr;
@@ -365,6 +366,77 @@ const HostLayer* need(rc_handle* h, const std::string& path, std::string& missin
   return &it->second;
 }
 
+// Geometry the fused per-ray kernel is written for: 3 proposal levels of 64 / 64 / 32 samples on grids of 6 / 7 / 8
+// levels, the level-2 density grid and the appearance grid with identical level geometry, power-of-two hash tables.
+bool fused_geometry_ok(rc_handle* h) {
+  const rc_config& c = h->cfg;
+  bool ok = c.num_levels == 3 && c.num_samples[0] == 64 && c.num_samples[1] == 64 && c.num_samples[2] == 32;
+  const int want_lv[4] = {6, 7, 8, 8}, want_f[4] = {1, 1, 4, 4};
+  for (int g = 0; g < 4 && ok; ++g)
+    ok = h->grids[g].dev.num_levels == want_lv[g] && h->grids[g].dev.num_features == want_f[g];
+  // the two half-waves of the last level look up the density / appearance grid with shared level geometry
+  ok = ok && h->grids[2].dev.bbox == h->grids[3].dev.bbox && h->grids[2].dev.precondition == h->grids[3].dev.precondition;
+  for (int l = 0; l < 8 && ok; ++l) {
+    const RcGridLevel &A = h->grids[2].dev.lvl[l], &B = h->grids[3].dev.lvl[l];
+    ok = A.dense == B.dense && A.size == B.size && A.mask == B.mask && A.entries == B.entries;
+  }
+  for (int g = 0; g < 4 && ok; ++g)        // hashed levels: power-of-two tables only (index = hash & mask)
+    for (int l = 0; l < h->grids[g].dev.num_levels && ok; ++l)
+      ok = h->grids[g].dev.lvl[l].dense || h->grids[g].dev.lvl[l].mask != 0;
+  return ok;
+}
+
+// Derived table copies of the fused kernel: interleaved level-2 pairs, cell tables of the dense levels.
+int build_fused_tables(rc_handle* h) {
+  int rc;
+  {
+    // level-2 density + appearance tables interleaved entry by entry (same index in both grids): [dens 4 | app 4]
+    for (int l = 0; l < h->grids[2].dev.num_levels; ++l) {
+      if (h->grids[2].dev.lvl[l].dense) continue;          // dense levels: cell tables below
+      const size_t entries = h->grids[2].dev.lvl[l].entries;
+      DevBuf& b = h->packs["pair_" + std::to_string(l)];
+      const size_t bytes = entries * 8 * sizeof(float);
+      if (b.bytes != bytes) {
+        if (b.p) RC_HIP(h, hipFree(b.p));
+        RC_HIP(h, hipMalloc((void**)&b.p, bytes));
+        b.bytes = bytes;
+      }
+      RC_HIP(h, hipMemcpy2D(b.p, 32, h->grids[2].dev.lvl[l].table, 16, 16, entries, hipMemcpyDeviceToDevice));
+      RC_HIP(h, hipMemcpy2D(b.p + 4, 32, h->grids[3].dev.lvl[l].table, 16, 16, entries, hipMemcpyDeviceToDevice));
+    }
+    // dense levels as cell tables (the 8 corners of every cell of the zero-padded volume side by side):
+    // proposal grids 0 / 1: 8 floats per cell; level-2 pair: 8 x [density 4 | appearance 4] per cell
+    auto cells = [&](const std::string& key, size_t floats, float** out) -> int {
+      DevBuf& b = h->packs[key];
+      if (b.bytes != floats * sizeof(float)) {
+        if (b.p) RC_HIP(h, hipFree(b.p));
+        RC_HIP(h, hipMalloc((void**)&b.p, floats * sizeof(float)));
+        b.bytes = floats * sizeof(float);
+      }
+      *out = b.p;
+      return RC_OK;
+    };
+    for (int g = 0; g < 3; ++g)
+      for (int l = 0; l < h->grids[g].dev.num_levels; ++l) {
+        const RcGridLevel& L = h->grids[g].dev.lvl[l];
+        if (!L.dense) continue;
+        const size_t ncell = (size_t)(L.size + 3) * (L.size + 3) * (L.size + 3);
+        float* dst = nullptr;
+        if (g < 2) {
+          if ((rc = cells("cell" + std::to_string(g) + "_" + std::to_string(l), ncell * 8, &dst))) return rc;
+          rc_launch_build_cells(L.table, L.size, 1, dst, 1, 0, nullptr);
+          h->grids[g].dev.lvl[l].cell = dst;       // the launch-per-stage gather reads it as well
+        } else {
+          if ((rc = cells("pair_" + std::to_string(l), ncell * 64, &dst))) return rc;      // replaces the flat pair table
+          rc_launch_build_cells(L.table, L.size, 4, dst, 8, 0, nullptr);
+          rc_launch_build_cells(h->grids[3].dev.lvl[l].table, L.size, 4, dst, 8, 4, nullptr);
+        }
+      }
+  }
+  RC_HIP(h, hipDeviceSynchronize());
+  return RC_OK;
+}
+
 int repack_transient(rc_handle* h);
 
 int repack(rc_handle* h) {
@@ -407,7 +479,25 @@ int repack(rc_handle* h) {
     int rc = upload(h, "dens_" + std::to_string(l), pad_stream(stream));
     if (rc) return rc;
   }
-  if (h->transient) return repack_transient(h);
+  if (h->transient) {
+    // front end of the time-resolved cache through the fused kernel's FRONT variant: [dens 0 | dens 1 | dens 2 (+ bwd)]
+    int off[4];
+    rc_fused_stream_offsets(&off[0], &off[1], &off[2], &off[3]);
+    bool ok = fused_geometry_ok(h);
+    std::vector<float> stream;
+    for (int p = 0; p < 3 && ok; ++p) {
+      ok = (int)(stream.size() / 64) == off[p];
+      append(stream, fused_parts[p]);
+    }
+    ok = ok && (int)(stream.size() / 64) == off[3];
+    h->fused_front_ok = ok;
+    if (ok) {
+      int rc = upload(h, "fused_front", pad_stream(stream));
+      if (rc) return rc;
+      if ((rc = build_fused_tables(h))) return rc;
+    }
+    return repack_transient(h);
+  }
   const std::string sh = "params/Cache/Shader";
   const HostLayer* bott = need(h, sh + "/bottleneck_layer", missing);
   const HostLayer* rough = need(h, sh + "/roughness_layer", missing);
@@ -487,19 +577,7 @@ int repack(rc_handle* h) {
     // hotdog layout only (3 levels of 64/64/32 samples, 6/7/32 density features, 32 appearance features)
     int off[4];
     const int nf = rc_fused_stream_offsets(&off[0], &off[1], &off[2], &off[3]);
-    bool ok = c.num_levels == 3 && c.num_samples[0] == 64 && c.num_samples[1] == 64 && c.num_samples[2] == 32;
-    const int want_lv[4] = {6, 7, 8, 8}, want_f[4] = {1, 1, 4, 4};
-    for (int g = 0; g < 4 && ok; ++g)
-      ok = h->grids[g].dev.num_levels == want_lv[g] && h->grids[g].dev.num_features == want_f[g];
-    // the two half-waves of the last level look up the density / appearance grid with shared level geometry
-    ok = ok && h->grids[2].dev.bbox == h->grids[3].dev.bbox && h->grids[2].dev.precondition == h->grids[3].dev.precondition;
-    for (int l = 0; l < 8 && ok; ++l) {
-      const RcGridLevel &A = h->grids[2].dev.lvl[l], &B = h->grids[3].dev.lvl[l];
-      ok = A.dense == B.dense && A.size == B.size && A.mask == B.mask && A.entries == B.entries;
-    }
-    for (int g = 0; g < 4 && ok; ++g)        // hashed levels: power-of-two tables only (index = hash & mask)
-      for (int l = 0; l < h->grids[g].dev.num_levels && ok; ++l)
-        ok = h->grids[g].dev.lvl[l].dense || h->grids[g].dev.lvl[l].mask != 0;
+    bool ok = fused_geometry_ok(h);
     std::vector<float> stream;
     for (int p = 0; p < 4 && ok; ++p) {
       ok = (int)(stream.size() / 64) == off[p];
@@ -510,49 +588,7 @@ int repack(rc_handle* h) {
     if (ok) {
       int rc = upload(h, "fused", pad_stream(stream));
       if (rc) return rc;
-      // level-2 density + appearance tables interleaved entry by entry (same index in both grids): [dens 4 | app 4]
-      for (int l = 0; l < h->grids[2].dev.num_levels; ++l) {
-        if (h->grids[2].dev.lvl[l].dense) continue;          // dense levels: cell tables below
-        const size_t entries = h->grids[2].dev.lvl[l].entries;
-        DevBuf& b = h->packs["pair_" + std::to_string(l)];
-        const size_t bytes = entries * 8 * sizeof(float);
-        if (b.bytes != bytes) {
-          if (b.p) RC_HIP(h, hipFree(b.p));
-          RC_HIP(h, hipMalloc((void**)&b.p, bytes));
-          b.bytes = bytes;
-        }
-        RC_HIP(h, hipMemcpy2D(b.p, 32, h->grids[2].dev.lvl[l].table, 16, 16, entries, hipMemcpyDeviceToDevice));
-        RC_HIP(h, hipMemcpy2D(b.p + 4, 32, h->grids[3].dev.lvl[l].table, 16, 16, entries, hipMemcpyDeviceToDevice));
-      }
-      // dense levels as cell tables (the 8 corners of every cell of the zero-padded volume side by side):
-      // proposal grids 0 / 1: 8 floats per cell; level-2 pair: 8 x [density 4 | appearance 4] per cell
-      auto cells = [&](const std::string& key, size_t floats, float** out) -> int {
-        DevBuf& b = h->packs[key];
-        if (b.bytes != floats * sizeof(float)) {
-          if (b.p) RC_HIP(h, hipFree(b.p));
-          RC_HIP(h, hipMalloc((void**)&b.p, floats * sizeof(float)));
-          b.bytes = floats * sizeof(float);
-        }
-        *out = b.p;
-        return RC_OK;
-      };
-      for (int g = 0; g < 3; ++g)
-        for (int l = 0; l < h->grids[g].dev.num_levels; ++l) {
-          const RcGridLevel& L = h->grids[g].dev.lvl[l];
-          if (!L.dense) continue;
-          const size_t ncell = (size_t)(L.size + 3) * (L.size + 3) * (L.size + 3);
-          float* dst = nullptr;
-          if (g < 2) {
-            if ((rc = cells("cell" + std::to_string(g) + "_" + std::to_string(l), ncell * 8, &dst))) return rc;
-            rc_launch_build_cells(L.table, L.size, 1, dst, 1, 0, nullptr);
-            h->grids[g].dev.lvl[l].cell = dst;       // the launch-per-stage gather reads it as well
-          } else {
-            if ((rc = cells("pair_" + std::to_string(l), ncell * 64, &dst))) return rc;      // replaces the flat pair table
-            rc_launch_build_cells(L.table, L.size, 4, dst, 8, 0, nullptr);
-            rc_launch_build_cells(h->grids[3].dev.lvl[l].table, L.size, 4, dst, 8, 4, nullptr);
-          }
-        }
-      RC_HIP(h, hipDeviceSynchronize());
+      if ((rc = build_fused_tables(h))) return rc;
     }
   }
   {
@@ -994,6 +1030,31 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     for (int i = 0; i <= ST_SHADER; ++i) stage_mark(h, slot, i, st);
     rc_launch_fused(F, st);
     for (int i = ST_SHADER + 1; i <= ST_COUNT; ++i) stage_mark(h, slot, i, st);
+    return;
+  }
+  if (A.tout && h->fused_front_ok && h->fused_mode != 0 && !secondary && !resample && !A.weights_only) {
+    // time-resolved cache on primary rays: the whole proposal sampler + appearance lookup as ONE launch (the FRONT
+    // variant of the fused kernel), results in the workspace buffers the stages behind it read
+    const std::string L2 = std::to_string(NL - 1);
+    RcFusedLaunch F{};
+    F.rays = A.rays; F.n = n;
+    for (int l = 0; l < 3; ++l) { F.jitter[l] = rnd ? rnd->jitter[l] : nullptr; F.num_samples[l] = c.num_samples[l]; }
+    for (int g = 0; g < 4; ++g) F.grid[g] = &h->grids[g].dev;
+    for (int l = 0; l < h->grids[2].dev.num_levels; ++l) F.pair_table[l] = h->packs["pair_" + std::to_string(l)].p;
+    for (int g = 0; g < 2; ++g)
+      for (int l = 0; l < h->grids[g].dev.num_levels; ++l)
+        F.cell_table[g][l] = h->grids[g].dev.lvl[l].dense ? h->packs["cell" + std::to_string(g) + "_" + std::to_string(l)].p : nullptr;
+    F.wstream = h->packs["fused_front"].p; F.ide_coef = nullptr;
+    F.anneal = c.anneal; F.padding = c.resample_padding; F.density_bias = c.density_bias;
+    F.contract_radius = c.contract_radius; F.bg = c.bg_intensity;
+    memset(&F.out, 0, sizeof(F.out));
+    F.front = 1;
+    F.want_grad = (A.out.ptr[RC_OUT_NORMALS] != nullptr || A.force_grad) ? 1 : 0;
+    F.use_raydist = 1; F.raydist_p = c.raydist_p; F.raydist_premult = c.raydist_premult;   // TransientNeRFModel (see below)
+    F.f_tdist = W(h, "tdist" + L2); F.f_density = W(h, "density" + L2); F.f_means = W(h, "means" + L2);
+    F.f_normals_pred = W(h, "normals_pred"); F.f_normals_grad = W(h, "normals_grad"); F.f_hbuf = W(h, "hbuf"); F.f_app = W(h, "app");
+    rc_launch_fused(F, st);
+    enqueue_transient_tail(h, A, st);
     return;
   }
   for (int l = 0; l < NL; ++l) {

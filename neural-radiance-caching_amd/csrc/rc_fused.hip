@@ -38,11 +38,11 @@ constexpr int F_L0 = 0;                              // K = 6: KS0 = 4
 constexpr int F_L1 = F_L0 + DensFrags<4>::B1;        // K = 7: KS0 = 5
 constexpr int F_L2 = F_L1 + DensFrags<5>::B1;        // K = 32: KS0 = 17, with the 96 backward fragments
 constexpr int F_SH = F_L2 + DensFrags<17>::END;
-constexpr int NF = F_SH + ShaderFrags::COUNT;
+constexpr int NF_FUSED = F_SH + ShaderFrags::COUNT;
 
 // Density MLP of a proposal level on 64 samples (two point-tiles); returns the raw density of
 // sample `lane`.  K grid features of this lane's sample are in f[].
-template <int K, int FB>
+template <int K, int FB, int NF>
 __device__ __forceinline__ float density_level64(const WStream& ws, float* act_wave, int lane, const float (&f)[K]) {
   constexpr int KS0 = (K + 1) / 2 + 1;
   using FR = DensFrags<KS0>;
@@ -96,10 +96,23 @@ struct RcFusedArgs {
   ShaderConsts sh;
   rc_outputs out;
   unsigned long long* stamps;
+  // FRONT variant (time-resolved cache): the proposal sampler only; what the launch-per-stage front end leaves in the
+  // workspace for the stages behind it, in its layouts (np = n * 32 shaded samples)
+  int32_t use_raydist; float raydist_p, raydist_premult, y_max;      // power-ladder distances (coord.py:223-260)
+  float* f_tdist;          // [n][33]
+  float* f_density;        // [np]
+  float* f_means;          // SoA [3][np]
+  float* f_normals_pred;   // SoA [3][np]
+  float* f_normals_grad;   // SoA [3][np] (GRAD) or nullptr
+  float* f_hbuf;           // [n][32 steps][64 lanes]: hidden feature in accumulator layout, one tile per ray
+  float* f_app;            // feature-major [32][np]
 };
 
-template <bool GRAD>
+// FRONT: stop behind the last proposal level (density MLP + appearance lookup) and hand the per-sample results to the
+// stages of the time-resolved cache; the stream then ends at F_SH.
+template <bool GRAD, bool FRONT = false>
 __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
+  constexpr int NF = FRONT ? F_SH : NF_FUSED;
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int64_t ray = (int64_t)blockIdx.x * kWaves + wave;
@@ -130,6 +143,15 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
     const bool hasj = a.jitter[level] != nullptr;
     const float jit = hasj ? a.jitter[level][ray] : 0.0f;
     sample_intervals_wave<false>(logit, P, S, a.us[level], hasj, jit, s_prev, s_cw, s_c, s_v, s_out, lane);
+    if constexpr (FRONT) {
+      if (a.use_raydist) {      // TransientNeRFModel samples its primary rays in power-ladder distance (models.py:122, 183-191)
+        const float s_near = power_ladder(near, a.raydist_p, a.raydist_premult), s_far = power_ladder(far, a.raydist_p, a.raydist_premult);
+        for (int e2 = lane; e2 <= S; e2 += 64)
+          s_td[e2] = inv_power_ladder(s_out[e2] * s_far + (1.0f - s_out[e2]) * s_near, a.raydist_p, a.raydist_premult, a.y_max);
+        lds_sync<false>();
+        return;
+      }
+    }
     for (int e2 = lane; e2 <= S; e2 += 64) s_td[e2] = s_out[e2] * far + (1.0f - s_out[e2]) * near;   // coord.py:259-260
     lds_sync<false>();
   };
@@ -174,7 +196,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
       }
     }
     RC_FSTAMP(2);
-    const float raw = density_level64<6, F_L0>(ws, act_wave, lane, f);
+    const float raw = density_level64<6, F_L0, NF>(ws, act_wave, lane, f);
     w = alpha_weight(density_of(raw, cx, cy, cz, a.grid[0].bbox), t0, t1, dnorm, true, lane);
   }
   RC_FSTAMP(3);
@@ -203,7 +225,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
       }
     }
     RC_FSTAMP(5);
-    const float raw = density_level64<7, F_L1>(ws, act_wave, lane, f);
+    const float raw = density_level64<7, F_L1, NF>(ws, act_wave, lane, f);
     w = alpha_weight(density_of(raw, cx, cy, cz, a.grid[1].bbox), t0, t1, dnorm, true, lane);
   }
   RC_FSTAMP(6);
@@ -350,7 +372,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
       }
       ngx = gzx / a.contract_radius; ngy = gzy / a.contract_radius; ngz = gzz / a.contract_radius;
       neg_normalize(ngx, ngy, ngz);
-    } else {
+    } else if constexpr (!FRONT) {
       // the stream is consumed strictly in order: step the ring over the unused backward fragments
 #pragma unroll
       for (int f = F_L2 + FR::B1; f < F_SH; ++f)
@@ -358,6 +380,27 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
     }
   }
   RC_FSTAMP(9);
+  if constexpr (FRONT) {
+    // hand-over to the stages behind the sampler, in the layouts of the launch-per-stage front end
+    if (ray_ok) {
+      const int64_t np = a.n * 32, p = ray * 32 + j;
+      for (int e2 = lane; e2 <= 32; e2 += 64) a.f_tdist[ray * 33 + e2] = s_td[e2];
+      if (h == 0) {
+        a.f_density[p] = density;
+        a.f_means[p] = mx; a.f_means[np + p] = my; a.f_means[2 * np + p] = mz;
+        a.f_normals_pred[p] = npx; a.f_normals_pred[np + p] = npy; a.f_normals_pred[2 * np + p] = npz;
+        if constexpr (GRAD) {
+          if (a.f_normals_grad) { a.f_normals_grad[p] = ngx; a.f_normals_grad[np + p] = ngy; a.f_normals_grad[2 * np + p] = ngz; }
+        }
+      }
+      float* hb = a.f_hbuf + ray * (32 * 64) + lane;
+#pragma unroll
+      for (int s = 0; s < 32; ++s) hb[s * 64] = act[s * 64];                 // hidden feature, accumulator layout
+#pragma unroll
+      for (int s = 0; s < 16; ++s) a.f_app[(int64_t)(2 * s + h) * np + p] = act[(kAppTmp + s) * 64];   // feature 2 s + h of point j
+    }
+    return;
+  }
   // ------------------------------------------------------------------ shader on the 32 samples
 #pragma unroll
   for (int s = 0; s < 16; ++s) act[(32 + s) * 64] = act[(kAppTmp + s) * 64];
@@ -481,7 +524,7 @@ void rc_launch_build_cells(const float* src, int N, int F, float* dst, int dst_s
 
 int rc_fused_stream_offsets(int* l0, int* l1, int* l2, int* sh) {
   *l0 = F_L0; *l1 = F_L1; *l2 = F_L2; *sh = F_SH;
-  return NF;
+  return NF_FUSED;
 }
 
 void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream) {
@@ -491,6 +534,8 @@ void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream) {
   if (rc_first_use_on_device(prepared)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   RcFusedArgs a{};
   a.origins = L.rays.origins; a.directions = L.rays.directions; a.viewdirs = L.rays.viewdirs; a.near = L.rays.near;
@@ -514,6 +559,15 @@ void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream) {
   }
 #endif
   dim3 grid((unsigned)((L.n + kWaves - 1) / kWaves)), block(kWaves * 64);
+  if (L.front) {
+    a.use_raydist = L.use_raydist; a.raydist_p = L.raydist_p; a.raydist_premult = L.raydist_premult;
+    a.y_max = L.raydist_p < 0.0f ? nextafterf((L.raydist_p - 1.0f) / L.raydist_p, -INFINITY) : 0.0f;       // as rc_launch_sample
+    a.f_tdist = L.f_tdist; a.f_density = L.f_density; a.f_means = L.f_means; a.f_normals_pred = L.f_normals_pred;
+    a.f_normals_grad = L.want_grad ? L.f_normals_grad : nullptr; a.f_hbuf = L.f_hbuf; a.f_app = L.f_app;
+    if (L.want_grad) hipLaunchKernelGGL((k_cache_fused<true, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((k_cache_fused<false, true>), grid, block, lds, stream, a);
+    return;
+  }
   if (L.out.ptr[RC_OUT_NORMALS]) hipLaunchKernelGGL(k_cache_fused<true>, grid, block, lds, stream, a);
   else hipLaunchKernelGGL(k_cache_fused<false>, grid, block, lds, stream, a);
 }

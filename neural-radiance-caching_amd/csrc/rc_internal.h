@@ -234,6 +234,11 @@ struct RcFusedLaunch {
   float anneal, padding, density_bias, contract_radius, bg; float pct[3];
   float roughness_bias, irradiance_bias, ambient_bias, rgb_max, slf_ambient_bias;
   rc_outputs out;
+  // front end only (time-resolved cache): stop behind the last proposal level, results into the workspace buffers of
+  // the launch-per-stage plan (wstream then ends at the shader's offset)
+  int32_t front, want_grad;
+  int32_t use_raydist; float raydist_p, raydist_premult;
+  float* f_tdist; float* f_density; float* f_means; float* f_normals_pred; float* f_normals_grad; float* f_hbuf; float* f_app;
 };
 int rc_fused_stream_offsets(int* l0, int* l1, int* l2, int* sh);   // returns the total fragment count
 void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream);

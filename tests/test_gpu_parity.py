@@ -810,3 +810,25 @@ def test_lean_resampling_pass_equals_the_full_one(rc):
     torch.cuda.synchronize()
     for k in plean:
         assert torch.equal(plean[k], pfull[k]), k
+
+
+@pytest.mark.parametrize("occ", [False, True])
+def test_transient_fused_front_end_equals_the_staged_one(occ):
+    """The proposal sampler of the time-resolved cache as ONE launch (FRONT variant of the fused kernel, power-ladder
+    distances) hands the stages behind it bit for bit what the launch-per-stage front end does."""
+    from nrc_amd import rc_ext
+    cfg = nrc_amd.cornell_transient_config(use_occlusions=occ)
+    h = rc_ext.RadianceCache(cfg, 0)
+    h.load_weights(common.weights_transient_np())
+    n = 203
+    rays = nrc_amd.synthetic_transient_rays(n)
+    rnd = {"jitter": common.jitters(n, seed=4)}
+    if occ:
+        rnd["shadow_jitter"] = common.shadow_jitters(n * 32, seed=6)      # one shadow ray per shaded sample
+    a = h.render_transient(rays.hot_fields(), rnd)
+    h.set_fused(False)
+    b = h.render_transient(rays.hot_fields(), rnd)
+    h.set_fused(True)
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
