@@ -41,7 +41,7 @@ assert FUSED_FLOP_PER_RAY == 9703424
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
 # per-launch FETCH_SIZE + WRITE_SIZE (KiB) of the dominant kernel, profiles/r01_pmc_summary.txt
-PMC_KIB = {"fused": 114069.6 + 248.0, "shader": 8656.1 + 1920.0}
+PMC_KIB = {"fused": 113985.5 + 248.0, "shader": 8656.1 + 1920.0}
 
 
 def host_cpu_share(cap=16):
