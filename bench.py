@@ -235,6 +235,11 @@ def main():
     args = ap.parse_args()
     if args.profile_mode == 3 and args.steps < 16:
         args.profile_mode = 2            # too few steps to sample: events on every step
+    # stdout carries exactly ONE line, the JSON: anything the GPU runtime or a library writes to file descriptor 1
+    # meanwhile (libdrm prints a missing-file notice there at device initialisation) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -376,7 +381,10 @@ def main():
         res["cpu_baseline"] = secondary("cpu_baseline", cpu_baseline, cfg, weights, RAYS_PER_BATCH)
     else:
         res["cpu_baseline"] = None
-    print(json.dumps(res))
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
+    os.close(json_fd)
+    print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
