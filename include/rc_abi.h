@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 1
+#define RC_ABI_VERSION 2
 #define RC_MAX_LEVELS 3
 
 typedef struct rc_handle rc_handle;
@@ -39,7 +39,8 @@ typedef enum {
   RC_ERR_MISSING_WEIGHT = -3,
   RC_ERR_SHAPE = -4,
   RC_ERR_UNSUPPORTED = -5,
-  RC_ERR_NO_DEVICE = -6
+  RC_ERR_NO_DEVICE = -6,
+  RC_ERR_HOST = -7             /* a C++ exception (e.g. std::bad_alloc) caught at the boundary */
 } rc_status;
 
 /* One multiresolution dense+hash encoding.
@@ -176,6 +177,11 @@ typedef struct {
   const float* vmf_tmp;           /* [n, Kd-Kc]   U[0,1) (render_utils.py:1413) */
   const float* sec_jitter[RC_MAX_LEVELS];  /* [n*(Ks+Kd)] per level: jitter of the secondary rays, block [n*Ks | n*Kd] */
   const float* sec_gumbel;        /* [n*(Ks+Kd), S_last] */
+  /* optional (NULL: draw from the Gumbel noise above): the categorical picks themselves, as rc_randoms.resample_inds
+   * does for rc_render_rays -- filtered_sampler_inds of the primary rays (models.py:1418-1438) and of the batched
+   * secondary trace (material.py:2191-2217 -> models.py:193-292).  With both given the noise members may be NULL. */
+  const int32_t* resample_inds;     /* [n]          */
+  const int32_t* sec_resample_inds; /* [n*(Ks+Kd)]  block [n*Ks | n*Kd] like sec_jitter */
 } rc_material_randoms;
 
 typedef enum {
@@ -208,7 +214,11 @@ const char* rc_last_error(const rc_handle* h);   /* h may be NULL: last error of
 int rc_abi_version(void);
 
 /* -- weights: replaces flax `variables` passed to model.apply (internal/train_utils.py:3796-3814)
- * May be called several times; tensors with unknown names are rejected. */
+ * May be called several times; tensors with unknown names are rejected.
+ * Ordering contract: the copies are blocking hipMemcpy calls on the null stream.  Device-resident sources
+ * (on_device = 1) must be complete when the call is made -- work still running on a non-blocking stream is not
+ * waited for; synchronise that stream (or the device) first, as the Python binding does.  The call returns after
+ * the copies have finished, and later render calls on any stream see the new weights. */
 int rc_load_weights(rc_handle* h, const rc_tensor_desc* descs, int32_t n);
 
 /* -- the hot path: replaces model.apply(variables, rng, rays, ...)["render"] for the cache stage

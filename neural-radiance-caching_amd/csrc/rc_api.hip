@@ -10,6 +10,7 @@
 
 #include <array>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -86,7 +87,14 @@ struct rc_handle {
   // workspace (ws_prefix selects the slot: "" / "p1:".. one per caller stream so that independent
   // batches enqueued on different streams overlap; "s:" batched secondary trace of the material stage)
   std::string ws_prefix;
-  std::vector<hipStream_t> slot_streams;
+  // Who used a workspace set last.  Sets 0-3 serve rc_render_rays (one per caller stream, least recently used one taken
+  // over when a fifth stream shows up); set 0 also serves rc_render_material / rc_render_transient (with its "s:"
+  // companion for their batched secondary trace); set 4 ("t:") serves rc_density_backward.  A call whose stream differs
+  // from the set's previous user first waits for that user's last call (event), so two streams never run on one set at
+  // the same time.
+  struct WsGroup { hipStream_t stream = nullptr; bool used = false; hipEvent_t done = nullptr; uint64_t last_use = 0; };
+  WsGroup groups[5];
+  uint64_t use_clock = 0;
   int64_t ws_rays = 0;
   std::map<std::string, DevBuf> ws;
   std::map<std::string, int64_t> ws_count;
@@ -131,6 +139,21 @@ int fail(rc_handle* h, int code, const std::string& msg) {
   h->err = msg;
   return code;
 }
+
+// Nothing may propagate out of an extern "C" entry point (include/rc_abi.h): std::bad_alloc / std::length_error of the
+// host-side containers end up here and come back as a status code.
+int rc_caught(rc_handle* h, const char* what) noexcept {
+  try {
+    const std::string msg = std::string("exception in the host layer: ") + (what ? what : "unknown");
+    if (h) h->err = msg; else g_create_error = msg;
+  } catch (...) {
+  }
+  return RC_ERR_HOST;
+}
+#define RC_TRY try {
+#define RC_CATCH(h)                                                       \
+  } catch (const std::exception& e_) { return rc_caught((h), e_.what()); } \
+  catch (...) { return rc_caught((h), nullptr); }
 
 std::vector<int> grid_sizes(const rc_grid_config& g) {
   // grid_utils.py:773-794 with scale_supersample = 1
@@ -655,11 +678,16 @@ int repack(rc_handle* h) {
 // ---------------------------------------------------------------------------------------------
 // Workspace
 // ---------------------------------------------------------------------------------------------
+void drop_graphs(rc_handle* h);
+
 int ws_alloc(rc_handle* h, const std::string& name0, int64_t count) {
   const std::string name = h->ws_prefix + name0;
   DevBuf& b = h->ws[name];
   const size_t bytes = (size_t)count * sizeof(float);
   if (b.bytes < bytes) {
+    // captured graphs have workspace pointers baked into their kernel arguments: none survives a reallocation
+    // (whichever entry point grew the buffer), so this is the one place that invalidates them
+    drop_graphs(h);
     if (b.p) RC_HIP(h, hipFree(b.p));
     RC_HIP(h, hipMalloc((void**)&b.p, bytes));
     b.bytes = bytes;
@@ -721,6 +749,28 @@ void stage_mark(rc_handle* h, int slot, int idx, hipStream_t s) {
   (void)hipEventRecord(h->ev[slot][idx], s);
 }
 
+int ws_enter(rc_handle* h, int g, hipStream_t st) {
+  rc_handle::WsGroup& G = h->groups[g];
+  if (!G.done) RC_HIP(h, hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
+  if (G.used && G.stream != st) RC_HIP(h, hipStreamWaitEvent(st, G.done, 0));
+  G.stream = st; G.used = true; G.last_use = ++h->use_clock;
+  return RC_OK;
+}
+int ws_leave(rc_handle* h, int g, hipStream_t st) {
+  RC_HIP(h, hipEventRecord(h->groups[g].done, st));
+  return RC_OK;
+}
+// Workspace set of rc_render_rays for caller stream `st`: its own, else a free one, else the least recently used.
+int ws_pick(rc_handle* h, hipStream_t st) {
+  int free_i = -1, lru = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (h->groups[i].used && h->groups[i].stream == st) return i;
+    if (!h->groups[i].used && free_i < 0) free_i = i;
+    if (h->groups[i].last_use < h->groups[lru].last_use) lru = i;
+  }
+  return free_i >= 0 ? free_i : lru;
+}
+
 void drop_graphs(rc_handle* h) {
   for (auto& g : h->graphs) {
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
@@ -762,6 +812,7 @@ const char* rc_stage_name(int32_t s) { return (s >= 0 && s < ST_COUNT) ? kStageN
 const char* rc_last_error(const rc_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int rc_create(const rc_config* cfg, int device, rc_handle** out) {
+  RC_TRY
   if (!cfg || !out) { g_create_error = "rc_create: null argument"; return RC_ERR_INVALID_ARG; }
   if (cfg->abi_version != RC_ABI_VERSION) { g_create_error = "rc_create: abi_version mismatch"; return RC_ERR_INVALID_ARG; }
   if (cfg->num_levels < 1 || cfg->num_levels > RC_MAX_LEVELS) { g_create_error = "rc_create: num_levels out of range"; return RC_ERR_INVALID_ARG; }
@@ -771,7 +822,8 @@ int rc_create(const rc_config* cfg, int device, rc_handle** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_error = "rc_create: no HIP device"; return RC_ERR_NO_DEVICE; }
   if (device < 0 || device >= ndev) { g_create_error = "rc_create: bad device index"; return RC_ERR_INVALID_ARG; }
   if (hipSetDevice(device) != hipSuccess) { g_create_error = "rc_create: hipSetDevice failed"; return RC_ERR_HIP; }
-  rc_handle* h = new rc_handle();
+  std::unique_ptr<rc_handle> hp(new rc_handle());
+  rc_handle* h = hp.get();
   h->cfg = *cfg;
   h->device = device;
   const rc_grid_config* gcfgs[6] = {&cfg->proposal_grids[0], &cfg->proposal_grids[1], &cfg->proposal_grids[2],
@@ -782,12 +834,10 @@ int rc_create(const rc_config* cfg, int device, rc_handle** out) {
   for (int g = 0; g < 6; ++g) {
     if (gcfgs[g]->num_features != 1 && gcfgs[g]->num_features != 4) {
       g_create_error = "rc_create: num_features must be 1 or 4";
-      delete h;
       return RC_ERR_UNSUPPORTED;
     }
     if ((int)grid_sizes(*gcfgs[g]).size() > RC_MAX_GRID_LEVELS) {
       g_create_error = "rc_create: too many grid levels";
-      delete h;
       return RC_ERR_UNSUPPORTED;
     }
     init_grid(h->grids[g], *gcfgs[g], prefixes[g]);
@@ -800,15 +850,16 @@ int rc_create(const rc_config* cfg, int device, rc_handle** out) {
   auto ks_ok = [](int K) { const int ks = (K + 1) / 2 + 1; return ks == 4 || ks == 5 || ks == 17; };
   if (cfg->num_levels != 3 || !ks_ok(K0) || !ks_ok(K1) || K2 != 32 || KA != 32) {
     g_create_error = "rc_create: unsupported grid feature widths (kernels are built for the hotdog/ngp_yobo shapes)";
-    delete h;
     return RC_ERR_UNSUPPORTED;
   }
-  *out = h;
+  *out = hp.release();
   return RC_OK;
+  RC_CATCH(nullptr)
 }
 
 void rc_destroy(rc_handle* h) {
   if (!h) return;
+  try {
   (void)hipSetDevice(h->device);
   for (auto& g : h->grids)
     for (auto& t : g.tables)
@@ -817,14 +868,18 @@ void rc_destroy(rc_handle* h) {
   for (auto& kv : h->ws) if (kv.second.p) (void)hipFree(kv.second.p);
   if (h->ide_table.p) (void)hipFree(h->ide_table.p);
   drop_graphs(h);
+  for (auto& G : h->groups) if (G.done) (void)hipEventDestroy(G.done);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   if (h->ev_created)
     for (int s = 0; s < kEvSlots; ++s)
       for (int i = 0; i <= ST_COUNT; ++i) (void)hipEventDestroy(h->ev[s][i]);
+  } catch (...) {
+  }
   delete h;
 }
 
 int rc_load_weights(rc_handle* h, const rc_tensor_desc* descs, int32_t n) {
+  RC_TRY
   if (!h) return RC_ERR_INVALID_ARG;
   if (!descs && n > 0) return fail(h, RC_ERR_INVALID_ARG, "rc_load_weights: null descs");
   RC_HIP(h, hipSetDevice(h->device));
@@ -895,9 +950,11 @@ int rc_load_weights(rc_handle* h, const rc_tensor_desc* descs, int32_t n) {
   }
   drop_graphs(h);   // table pointers / packed fragments are baked into captured kernel arguments
   return RC_OK;
+  RC_CATCH(h)
 }
 
 int rc_set_profiling(rc_handle* h, int32_t enabled) {
+  RC_TRY
   if (!h) return RC_ERR_INVALID_ARG;
   RC_HIP(h, hipSetDevice(h->device));
   if (enabled && !h->ev_created) {
@@ -910,25 +967,31 @@ int rc_set_profiling(rc_handle* h, int32_t enabled) {
   h->prof_calls = 0;
   for (int s = 0; s < kEvSlots; ++s) h->ev_used[s] = false;
   return RC_OK;
+  RC_CATCH(h)
 }
 
 int rc_set_fused(rc_handle* h, int32_t mode) {
+  RC_TRY
   if (!h) return RC_ERR_INVALID_ARG;
   if (mode < 0 || mode > 1) return fail(h, RC_ERR_INVALID_ARG, "rc_set_fused: mode must be 0 or 1");
   if (mode != h->fused_mode) drop_graphs(h);
   h->fused_mode = mode;
   return RC_OK;
+  RC_CATCH(h)
 }
 
 int rc_set_graph_mode(rc_handle* h, int32_t mode) {
+  RC_TRY
   if (!h) return RC_ERR_INVALID_ARG;
   if (mode < 0 || mode > 2) return fail(h, RC_ERR_INVALID_ARG, "rc_set_graph_mode: mode must be 0, 1 or 2");
   h->graph_mode = mode;
   if (mode == 0) drop_graphs(h);
   return RC_OK;
+  RC_CATCH(h)
 }
 
 int rc_stage_times_ms(rc_handle* h, float* out_ms, int32_t n) {
+  RC_TRY
   if (!h || !out_ms) return RC_ERR_INVALID_ARG;
   if (!h->ev_created) return fail(h, RC_ERR_INVALID_ARG, "rc_stage_times_ms: profiling was not enabled");
   RC_HIP(h, hipSetDevice(h->device));
@@ -948,19 +1011,23 @@ int rc_stage_times_ms(rc_handle* h, float* out_ms, int32_t n) {
   if (!used) return fail(h, RC_ERR_INVALID_ARG, "rc_stage_times_ms: no profiled render call yet");
   for (int i = 0; i < ST_COUNT && i < n; ++i) out_ms[i] = (float)(sum[i] / used);
   return RC_OK;
+  RC_CATCH(h)
 }
 
 int rc_workspace_ptr(rc_handle* h, const char* name, void** ptr, int64_t* count) {
+  RC_TRY
   if (!h || !name || !ptr || !count) return RC_ERR_INVALID_ARG;
   auto it = h->ws.find(name);
   if (it == h->ws.end()) return fail(h, RC_ERR_INVALID_ARG, std::string("rc_workspace_ptr: unknown buffer ") + name);
   *ptr = it->second.p;
   *count = h->ws_count[name];
   return RC_OK;
+  RC_CATCH(h)
 }
 
 int rc_hashgrid_lookup(rc_handle* h, int32_t grid_id, const float* points, int64_t n, float* features_out,
                        int32_t apply_contraction, void* stream) {
+  RC_TRY
   if (!h) return RC_ERR_INVALID_ARG;
   if (grid_id < 0 || grid_id >= 6) return fail(h, RC_ERR_INVALID_ARG, "rc_hashgrid_lookup: bad grid_id");
   if (n < 0 || (n > 0 && (!points || !features_out))) return fail(h, RC_ERR_INVALID_ARG, "rc_hashgrid_lookup: null buffer");
@@ -973,10 +1040,12 @@ int rc_hashgrid_lookup(rc_handle* h, int32_t grid_id, const float* points, int64
                      nullptr, (hipStream_t)stream);
   RC_HIP(h, hipGetLastError());
   return RC_OK;
+  RC_CATCH(h)
 }
 
 int rc_sample_intervals(rc_handle* h, const float* t, const float* logits, int64_t n, int32_t num_bins,
                         int32_t num_samples, const float* jitter, float* out, void* stream) {
+  RC_TRY
   if (!h) return RC_ERR_INVALID_ARG;
   if (num_bins < 1 || num_bins > 64 || num_samples < 2 || num_samples > 64)
     return fail(h, RC_ERR_UNSUPPORTED, "rc_sample_intervals: bins/samples must be <= 64 (samples >= 2)");
@@ -985,6 +1054,7 @@ int rc_sample_intervals(rc_handle* h, const float* t, const float* logits, int64
   rc_launch_sample_intervals(t, logits, n, num_bins, num_samples, jitter, out, (hipStream_t)stream);
   RC_HIP(h, hipGetLastError());
   return RC_OK;
+  RC_CATCH(h)
 }
 
 namespace {
@@ -1207,6 +1277,7 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
 
 int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_randoms* rnd, uint32_t pass_mask,
                    const rc_outputs* out, void* stream_v) {
+  RC_TRY
   if (!h) return RC_ERR_INVALID_ARG;
   if (!rays || !out) return fail(h, RC_ERR_INVALID_ARG, "rc_render_rays: null rays/outputs");
   if (n < 0) return fail(h, RC_ERR_INVALID_ARG, "rc_render_rays: negative n_rays");
@@ -1229,27 +1300,23 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_random
   }
   if (secondary && !(pass_mask & RC_PASS_NO_ENVMAP) && !h->have_envmap)
     return fail(h, RC_ERR_MISSING_WEIGHT, "missing weight: params/Cache/EnvMap/* (secondary rays composite the model-level EnvMap)");
-  // one workspace slot per caller stream (up to 4): calls on different streams do not share buffers
-  int ws_slot = 0;
-  {
-    size_t i = 0;
-    for (; i < h->slot_streams.size(); ++i) if (h->slot_streams[i] == st) break;
-    if (i == h->slot_streams.size()) {
-      if (h->slot_streams.size() < 4) h->slot_streams.push_back(st);
-      else i = 0;   // more than 4 streams: fall back to the first slot (stream order then serialises)
-    }
-    ws_slot = (int)i;
-  }
+  const bool fused = h->fused_mode != 0 && h->fused_ok && pass_mask == RC_PASS_CACHE;
+  // one workspace set per caller stream (up to 4): calls on different streams do not share buffers.  The fused kernel
+  // keeps every intermediate on chip: no workspace, no set.
+  const int ws_slot = fused ? 0 : ws_pick(h, st);
   struct PrefixGuard {
     rc_handle* h;
     ~PrefixGuard() { h->ws_prefix = ""; }
   } guard{h};
   h->ws_prefix = ws_slot == 0 ? "" : "p" + std::to_string(ws_slot) + ":";
-  const bool fused = h->fused_mode != 0 && h->fused_ok && pass_mask == RC_PASS_CACHE;
-  if (!fused) {   // the fused kernel keeps every intermediate on chip: no workspace
-    if (h->ws_count.find(h->ws_prefix + "acc_ws") == h->ws_count.end() || h->ws_count[h->ws_prefix + "acc_ws"] < n) drop_graphs(h);
-    if ((rc = ensure_workspace(h, n))) return rc;
+  if (!fused) {
+    if ((rc = ws_enter(h, ws_slot, st))) return rc;
+    if ((rc = ensure_workspace(h, n))) return rc;      // a reallocation drops the captured graphs (ws_alloc)
   }
+  struct LeaveGuard {                                  // every exit below records the set's "done" event
+    rc_handle* h; int slot; hipStream_t st; bool on;
+    ~LeaveGuard() { if (on) (void)ws_leave(h, slot, st); }
+  } leave{h, ws_slot, st, !fused};
   rc_shader_prepare();
 
   RenderArgs A{};
@@ -1318,11 +1385,13 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_random
   h->graphs.push_back(e);
   RC_HIP(h, hipGraphLaunch(e.exec, st));
   return RC_OK;
+  RC_CATCH(h)
 }
 
 int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_randoms* rnd,
                        const rc_material_randoms* mr, int32_t K, const rc_outputs* cache_out,
                        const rc_mat_outputs* mat_out, void* stream_v) {
+  RC_TRY
   if (!h) return RC_ERR_INVALID_ARG;
   if (h->transient) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_material: this handle renders the time-resolved cache (rc_render_transient)");
   if (!rays || !mr || !cache_out || !mat_out) return fail(h, RC_ERR_INVALID_ARG, "rc_render_material: null argument");
@@ -1337,9 +1406,11 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
   if (K < 2 || Ks < 1 || Kd < 2 || Kc < 1 || Kd - Kc < 1 || Ks + Kd > 64)
     return fail(h, RC_ERR_UNSUPPORTED, "rc_render_material: num_secondary_samples must give 1 <= Ks, 2 <= Kd, Ks + Kd <= 64");
   if (c.num_vmf != 128) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_material: num_vmf must be 128");
-  if (!mr->gumbel || !mr->vmf_noise || !mr->spec_u1 || !mr->spec_u2 || !mr->cos_u1 || !mr->cos_u2 || !mr->vmf_lobe ||
-      !mr->vmf_v || !mr->vmf_tmp || !mr->sec_gumbel)
-    return fail(h, RC_ERR_INVALID_ARG, "rc_render_material: every rc_material_randoms member except sec_jitter is required");
+  if (!mr->vmf_noise || !mr->spec_u1 || !mr->spec_u2 || !mr->cos_u1 || !mr->cos_u2 || !mr->vmf_lobe || !mr->vmf_v || !mr->vmf_tmp)
+    return fail(h, RC_ERR_INVALID_ARG, "rc_render_material: every sampler member of rc_material_randoms is required");
+  if (!(mr->gumbel || mr->resample_inds) || !(mr->sec_gumbel || mr->sec_resample_inds))
+    return fail(h, RC_ERR_INVALID_ARG, "rc_render_material: the categorical picks need gumbel or resample_inds (primary) and "
+                                       "sec_gumbel or sec_resample_inds (secondary trace)");
   RC_HIP(h, hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream_v;
   int rc;
@@ -1353,6 +1424,11 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
   const int S2 = c.num_samples[NL - 1];
   const int64_t np2 = n * S2, nsec = n * (Ks + Kd);
   h->ws_prefix = "";
+  if ((rc = ws_enter(h, 0, st))) return rc;             // shares workspace set 0 (and "s:") with the other entry points
+  struct LeaveGuard {
+    rc_handle* h; hipStream_t st;
+    ~LeaveGuard() { (void)ws_leave(h, 0, st); }
+  } leave{h, st};
   if ((rc = ensure_workspace(h, n))) return rc;
   if ((rc = ws_alloc(h, "m_pts", 3 * n)) || (rc = ws_alloc(h, "m_nrm", 3 * n)) || (rc = ws_alloc(h, "m_feat", 32 * n)) ||
       (rc = ws_alloc(h, "m_mat", RC_MAT_CH * n)) || (rc = ws_alloc(h, "m_feat_all", 32 * np2)) ||
@@ -1380,7 +1456,7 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
   {
     RcResampleArgs ra{};
     ra.n_rays = n; ra.S = S2; ra.tdist = W(h, "tdist" + LL); ra.density = W(h, "density" + LL);
-    ra.directions = rays->directions; ra.gumbel = mr->gumbel; ra.inds_in = nullptr;
+    ra.directions = rays->directions; ra.gumbel = mr->gumbel; ra.inds_in = mr->resample_inds;
     ra.inds_out = (int32_t*)W(h, "inds"); ra.filt_weight = W(h, "filt_weight"); ra.weights = W(h, "weights" + LL);
     rc_launch_resample(ra, st);
     hipLaunchKernelGGL(k_make_src, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const int32_t*)W(h, "inds"),
@@ -1440,7 +1516,7 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     B.rays.near = W(h, "sec_near"); B.rays.far = W(h, "sec_far"); B.rays.lights = W(h, "sec_lights"); B.rays.normals = nullptr;
     B.have_rnd = true;
     for (int l = 0; l < RC_MAX_LEVELS; ++l) B.rnd.jitter[l] = mr->sec_jitter[l];
-    B.rnd.gumbel = mr->sec_gumbel; B.rnd.resample_inds = nullptr;
+    B.rnd.gumbel = mr->sec_gumbel; B.rnd.resample_inds = mr->sec_resample_inds;
     B.n = nsec; B.mask = RC_PASS_CACHE | RC_PASS_SECONDARY | RC_PASS_NO_ENVMAP; B.slot = -1;
     memset(&B.out, 0, sizeof(B.out));
     B.out.ptr[RC_OUT_RGB] = W(h, "sec_rgb"); B.out.ptr[RC_OUT_ACC] = W(h, "sec_acc");
@@ -1466,6 +1542,7 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
   }
   RC_HIP(h, hipGetLastError());
   return RC_OK;
+  RC_CATCH(h)
 }
 
 }  // extern "C"

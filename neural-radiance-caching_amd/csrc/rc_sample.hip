@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_resample(RcResampleArgs
   const float p = e / wave_sum(e);
   int ind;
   if (a.inds_in) {
-    ind = a.inds_in[ray];
+    ind = min(max(a.inds_in[ray], 0), S - 1);     // caller-provided: keep the gathers behind it in range
   } else {
     // jax.random.categorical == argmax(logits + gumbel); first index on ties
     float key = act ? logit + a.gumbel[ray * S + lane] : -INFINITY;

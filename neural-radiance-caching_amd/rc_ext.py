@@ -14,7 +14,7 @@ import numpy as np
 
 from .config import GridConfig, RenderConfig
 
-RC_ABI_VERSION = 1
+RC_ABI_VERSION = 2
 RC_MAX_LEVELS = 3
 
 RC_PASS_CACHE = 0x1
@@ -93,7 +93,8 @@ RC_MOUT_COUNT = len(MAT_OUTPUTS)
 class rc_material_randoms(C.Structure):
     _fields_ = [("gumbel", C.c_void_p), ("vmf_noise", C.c_void_p), ("spec_u1", C.c_void_p), ("spec_u2", C.c_void_p),
                 ("cos_u1", C.c_void_p), ("cos_u2", C.c_void_p), ("vmf_lobe", C.c_void_p), ("vmf_v", C.c_void_p),
-                ("vmf_tmp", C.c_void_p), ("sec_jitter", C.c_void_p * RC_MAX_LEVELS), ("sec_gumbel", C.c_void_p)]
+                ("vmf_tmp", C.c_void_p), ("sec_jitter", C.c_void_p * RC_MAX_LEVELS), ("sec_gumbel", C.c_void_p),
+                ("resample_inds", C.c_void_p), ("sec_resample_inds", C.c_void_p)]
 
 
 class rc_mat_outputs(C.Structure):
@@ -333,6 +334,10 @@ class RadianceCache:
             for k, s in enumerate(shape):
                 descs[i].shape[k] = s
             descs[i].on_device = on_dev
+        # rc_load_weights copies with blocking hipMemcpy on the null stream, which is NOT ordered against torch's
+        # non-blocking side streams: finish whatever produced device-resident tensors first (an optimizer step)
+        if any(isinstance(w, torch.Tensor) and w.is_cuda for w in weights.values()):
+            torch.cuda.synchronize(self.device)
         self._check(self.lib.rc_load_weights(self._h, descs, len(weights)))
 
     # -- hot path ---------------------------------------------------------------------------
@@ -603,7 +608,8 @@ class RadianceCache:
     def render_material(self, rays: Dict[str, object], randoms: Dict[str, object], num_secondary_samples: int = None):
         """Material stage (rc_render_material).  randoms: dict with the keys of
         oracle-compatible `draw_randoms` (jitter[3], gumbel, vmf_noise, spec_u1/u2, cos_u1/u2, vmf_lobe, vmf_v,
-        vmf_tmp, spec_jitter[3], spec_gumbel, diff_jitter[3], diff_gumbel).
+        vmf_tmp, spec_jitter[3], spec_gumbel, diff_jitter[3], diff_gumbel) and optionally the categorical picks
+        themselves (resample_inds [n]; spec_resample_inds [n*Ks] + diff_resample_inds [n*Kd]), which replace the draws.
         Returns (cache_outputs, material_outputs) as dicts of cuda tensors."""
         torch = self._torch
         K = num_secondary_samples or self.cfg.num_secondary_samples
@@ -616,6 +622,8 @@ class RadianceCache:
                 rnd.jitter[l] = held[f"jit{l}"].data_ptr()
         mr = rc_material_randoms()
         for k in ("gumbel", "vmf_noise", "spec_u1", "spec_u2", "cos_u1", "cos_u2", "vmf_v", "vmf_tmp"):
+            if k == "gumbel" and randoms.get(k) is None:
+                continue                      # the primary pick is handed over as resample_inds
             held["m_" + k] = self._dev(randoms[k])
             setattr(mr, k, held["m_" + k].data_ptr())
         held["m_lobe"] = self._dev(randoms["vmf_lobe"], torch.int32).reshape(-1)
@@ -625,8 +633,17 @@ class RadianceCache:
             held[f"sj{l}"] = torch.cat([self._dev(randoms["spec_jitter"][l]).reshape(-1),
                                         self._dev(randoms["diff_jitter"][l]).reshape(-1)])
             mr.sec_jitter[l] = held[f"sj{l}"].data_ptr()
-        held["sg"] = torch.cat([self._dev(randoms["spec_gumbel"]), self._dev(randoms["diff_gumbel"])], dim=0).contiguous()
-        mr.sec_gumbel = held["sg"].data_ptr()
+        if randoms.get("spec_gumbel") is not None and randoms.get("diff_gumbel") is not None:
+            held["sg"] = torch.cat([self._dev(randoms["spec_gumbel"]), self._dev(randoms["diff_gumbel"])], dim=0).contiguous()
+            mr.sec_gumbel = held["sg"].data_ptr()
+        # explicit categorical picks (filtered_sampler_inds) instead of the Gumbel draws
+        if randoms.get("resample_inds") is not None:
+            held["m_inds"] = self._dev(randoms["resample_inds"], torch.int32).reshape(-1)
+            mr.resample_inds = held["m_inds"].data_ptr()
+        if randoms.get("spec_resample_inds") is not None and randoms.get("diff_resample_inds") is not None:
+            held["s_inds"] = torch.cat([self._dev(randoms["spec_resample_inds"], torch.int32).reshape(-1),
+                                        self._dev(randoms["diff_resample_inds"], torch.int32).reshape(-1)])
+            mr.sec_resample_inds = held["s_inds"].data_ptr()
         cout, mout = rc_outputs(), rc_mat_outputs()
         cres, mres = {}, {}
         c_items = [(i, nm, width) for i, (nm, width) in enumerate(OUTPUTS) if nm not in ("env_map_rgb", "rgb_no_env")]

@@ -274,7 +274,7 @@ def draw_randoms(cfg, n_rays, seed=0):
 # ----------------------------------------------------------------------------
 # The material stage
 # ----------------------------------------------------------------------------
-def _secondary_trace(weights, cfg, origins, dirs, lights, jitter, gumbel):
+def _secondary_trace(weights, cfg, origins, dirs, lights, jitter, gumbel, inds=None):
     """_make_radiance_cache_fn: cache(is_secondary=True, resample=True, use_env_map=False), normals=None
     (MaterialMLP.shadow_eps_indirect=False), near = MaterialMLP.near_min, far = Config.secondary_far."""
     n = origins.shape[0]
@@ -283,10 +283,12 @@ def _secondary_trace(weights, cfg, origins, dirs, lights, jitter, gumbel):
                 near=torch.full((n, 1), cfg.secondary_near, dtype=dt), far=torch.full((n, 1), cfg.secondary_far, dtype=dt),
                 lossmult=torch.ones((n, 1), dtype=dt))
     out = cache_ref.cache_forward(weights, cfg, rays, [torch.as_tensor(j)[:, None] for j in jitter], is_secondary=True,
-                                  gumbel=torch.as_tensor(gumbel), use_env_map=False, want_grad_normals=False)
+                                  gumbel=None if gumbel is None else torch.as_tensor(gumbel),
+                                  inds=None if inds is None else torch.as_tensor(inds).long().reshape(-1, 1),
+                                  use_env_map=False, want_grad_normals=False)
     r = out["render"]
     rgb = torch.clamp(mathx.nan_to_num(r["rgb"]), min=0.0)
-    return rgb, r["acc"]
+    return rgb, r["acc"], out["filtered_sampler_inds"]
 
 
 def material_forward(weights, cfg, rays, rnd, want_grad_normals=False):
@@ -299,7 +301,11 @@ def material_forward(weights, cfg, rays, rnd, want_grad_normals=False):
                                     want_grad_normals=want_grad_normals)
     geo = cache["sampler"][-1]
     # --- _get_material_samples: categorical resample to one sample per ray
-    filt, inds = cache_ref.maybe_resample(cfg, geo, True, gumbel=T(rnd["gumbel"]))
+    # rnd["resample_inds"] / rnd["{spec,diff}_resample_inds"] (optional) hand the categorical picks over instead of
+    # drawing them from the Gumbel noise (what rc_material_randoms.resample_inds / .sec_resample_inds do for the HIP path)
+    pin = rnd.get("resample_inds")
+    filt, inds = cache_ref.maybe_resample(cfg, geo, True, gumbel=None if rnd.get("gumbel") is None else T(rnd["gumbel"]),
+                                          inds=None if pin is None else torch.as_tensor(pin).long().reshape(-1, 1))
     R = rays["origins"].shape[0]
     pts = filt["means"][:, 0]                       # [R, 3]
     nrm = filt["normals_to_use"][:, 0]
@@ -315,14 +321,15 @@ def material_forward(weights, cfg, rays, rnd, want_grad_normals=False):
                           T(rnd["vmf_v"]), T(rnd["vmf_tmp"]))
     integ = {}
     dbg = {}
-    for name, s, kind, jit, gum in (("specular", spec, "microfacet_specular", rnd["spec_jitter"], rnd["spec_gumbel"]),
-                                    ("diffuse", diff, "microfacet_diffuse", rnd["diff_jitter"], rnd["diff_gumbel"])):
+    for name, s, kind, jit, gum, sinds in (
+            ("specular", spec, "microfacet_specular", rnd["spec_jitter"], rnd.get("spec_gumbel"), rnd.get("spec_resample_inds")),
+            ("diffuse", diff, "microfacet_diffuse", rnd["diff_jitter"], rnd.get("diff_gumbel"), rnd.get("diff_resample_inds"))):
         K = s["local_lightdirs"].shape[1]
         s["weight"] = torch.where(s["local_lightdirs"][..., 2:] > 0.0, s["weight"], torch.zeros_like(s["weight"]))
         o = origins[:, None, :].expand(-1, K, -1).reshape(-1, 3)
         d = s["global_lightdirs"].reshape(-1, 3)
         lg = rays["lights"][:, None, :].expand(-1, K, -1).reshape(-1, 3)
-        rgb, acc = _secondary_trace(weights, cfg, o, d, lg, [T(j) for j in jit], T(gum))
+        rgb, acc, sec_inds = _secondary_trace(weights, cfg, o, d, lg, [T(j) for j in jit], None if gum is None else T(gum), sinds)
         # indirect: radiance from the cache
         s_ind = dict(s, radiance_in=mathx.nan_to_num(rgb).reshape(R, K, 3), indirect_occ=acc.reshape(R, K, 1))
         integ["indirect_" + name] = integrate_reflect_rays(kind, mat, s_ind, cfg.rgb_max)
@@ -331,7 +338,8 @@ def material_forward(weights, cfg, rays, rnd, want_grad_normals=False):
         s_dir = dict(s, radiance_in=mathx.nan_to_num(env).reshape(R, K, 3), indirect_occ=acc.reshape(R, K, 1))
         integ["direct_" + name] = integrate_reflect_rays(kind, mat, s_dir, cfg.rgb_max)
         dbg[name] = dict(origins=o, dirs=d, pdf=s["pdf"], weight=s["weight"], local_lightdirs=s["local_lightdirs"],
-                         rgb=rgb, acc=acc, env=env)
+                         local_viewdirs=s["local_viewdirs"],
+                         rgb=rgb, acc=acc, env=env, inds=sec_inds[:, 0])
     # --- integration strategy (material.py:2705-2808)
     ro = lambda a, b: integ[a + "_" + b]["radiance_out"]
     sh = {}

@@ -87,7 +87,28 @@ def transient_case(n_rays, jitter_seed, name, occlusions=False, shadow_jitter_se
     print(name, sorted(d.keys())[:6], "...")
 
 
+def material_case(n_rays, rays_seed, rnd_seed, name):
+    """Material stage (configs[2]) on the smooth weight set in float64: the render dict plus the categorical picks of
+    the primary rays and of the secondary trace (handed to the HIP path through rc_material_randoms.*resample_inds)."""
+    from oracle import material_ref
+    cfg = nrc_amd.hotdog_config()
+    wt = common.to_torch(common.weights_material_np(True), F64)
+    rays = nrc_amd.synthetic_rays(n_rays, seed=rays_seed)
+    rnd = material_ref.draw_randoms(cfg, n_rays, seed=rnd_seed)
+    out = material_ref.material_forward(wt, cfg, common.rays_torch(rays, F64), rnd)
+    d = {"render_" + k: v.numpy().astype(np.float32) for k, v in out["render"].items()}
+    d["inds"] = out["inds"][:, 0].numpy().astype(np.int8)
+    d["spec_inds"] = out["debug"]["specular"]["inds"].numpy().astype(np.int8)
+    d["diff_inds"] = out["debug"]["diffuse"]["inds"].numpy().astype(np.int8)
+    d["meta"] = np.array([n_rays, rays_seed, rnd_seed], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, name), **d)
+    print(name, sorted(d.keys())[:6], "...")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "material":        # only the material fixture
+        material_case(64, 78, 5, "hotdog_material_64_smooth.npz")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "transient":       # only the transient fixtures
         transient_case(16, None, "transient_16_det.npz")
         transient_case(16, 5, "transient_16_jit.npz")
@@ -96,6 +117,7 @@ if __name__ == "__main__":
     transient_case(16, None, "transient_16_det.npz")
     transient_case(16, 5, "transient_16_jit.npz")
     transient_case(8, 5, "transient_8_occ.npz", occlusions=True, shadow_jitter_seed=13)
+    material_case(64, 78, 5, "hotdog_material_64_smooth.npz")
     cache_case(256, None, 0.0, "hotdog_cache_256_det.npz")
     cache_case(256, 7, 0.0, "hotdog_cache_256_jit.npz")
     cache_case(64, 11, 4.0, "hotdog_cache_64_shell.npz")

@@ -1,0 +1,108 @@
+"""Host-side robustness of the C ABI on the device: graph replay after workspace growth, more caller streams than
+workspace sets, entry points sharing a workspace set from different streams, error codes instead of exceptions."""
+import numpy as np
+import pytest
+import torch
+
+import common
+import nrc_amd
+
+pytestmark = pytest.mark.gpu
+
+STAGED = dict(outputs=["rgb", "acc", "distance_median", "normals_pred"])
+
+
+def _staged_rc(weights):
+    from nrc_amd import rc_ext
+    rc = rc_ext.RadianceCache(nrc_amd.hotdog_config(), 0)
+    rc.load_weights(weights)
+    rc.set_fused(False)            # the launch-per-stage plan: workspace + hipGraph replay
+    return rc
+
+
+def test_graph_replay_survives_workspace_growth_by_another_entry_point():
+    """A captured small-n render, then rc_render_material with a larger n (reallocates workspace set 0), then the small
+    render again: must equal an eager launch (the stale graph would read freed buffers)."""
+    from oracle import material_ref
+    cfg = nrc_amd.hotdog_config()
+    rc = _staged_rc(common.weights_material_np(True))
+    rc.set_graph_mode(2)           # capture on first sight
+    small = nrc_amd.synthetic_rays(64, seed=5).hot_fields()
+    bufs = rc.render_rays(small, None, **STAGED)
+    first = {k: v.clone() for k, v in rc.render_rays(small, None, out=bufs).items()}     # replay of the capture
+    torch.cuda.synchronize()
+    n = 256
+    rays = nrc_amd.synthetic_rays(n, seed=6)
+    rc.render_material(rays.hot_fields(), material_ref.draw_randoms(cfg, n, seed=1))      # grows every buffer
+    again = rc.render_rays(small, None, out=bufs)
+    torch.cuda.synchronize()
+    again = {k: v.clone() for k, v in again.items()}
+    rc.set_graph_mode(0)
+    eager = rc.render_rays(small, None, **STAGED)
+    torch.cuda.synchronize()
+    for k in eager:
+        assert torch.equal(first[k], eager[k]), k
+        assert torch.equal(again[k], eager[k]), k
+
+
+def test_more_streams_than_workspace_sets():
+    """Six caller streams on the launch-per-stage plan (four workspace sets): the fifth and sixth take over the least
+    recently used sets and are ordered behind their previous users; every result equals the single-stream one."""
+    rc = _staged_rc(common.weights_np())
+    rc.set_graph_mode(0)
+    n = 512
+    batches = [nrc_amd.synthetic_rays(n, seed=100 + i).hot_fields() for i in range(6)]
+    dev = [{k: rc._dev(v) for k, v in b.items() if v is not None} for b in batches]
+    want = []
+    for b in dev:
+        want.append({k: v.clone() for k, v in rc.render_rays(b, None, **STAGED).items()})
+        torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(6)]
+    for rep in range(3):
+        got = []
+        for s, b in zip(streams, dev):
+            with torch.cuda.stream(s):
+                got.append(rc.render_rays(b, None, **STAGED))
+        torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            for k in w:
+                assert torch.equal(g[k], w[k]), (rep, k)
+
+
+def test_material_and_cache_calls_from_two_streams_share_set_zero():
+    """rc_render_material always works in workspace set 0; a staged rc_render_rays on another stream that owns set 0 is
+    ordered against it instead of racing."""
+    from oracle import material_ref
+    cfg = nrc_amd.hotdog_config()
+    rc = _staged_rc(common.weights_material_np(True))
+    rc.set_graph_mode(0)
+    n = 256
+    rays = nrc_amd.synthetic_rays(n, seed=8)
+    rnd = material_ref.draw_randoms(cfg, n, seed=2)
+    fields = {k: rc._dev(v) for k, v in rays.hot_fields().items() if v is not None}
+    want_c = {k: v.clone() for k, v in rc.render_rays(fields, None, **STAGED).items()}
+    _, want_m = rc.render_material(fields, rnd)
+    want_m = {k: v.clone() for k, v in want_m.items()}
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            got_c = rc.render_rays(fields, None, **STAGED)
+        with torch.cuda.stream(s2):
+            _, got_m = rc.render_material(fields, rnd)
+        torch.cuda.synchronize()
+        for k in want_c:
+            assert torch.equal(got_c[k], want_c[k]), k
+        for k in want_m:
+            assert torch.equal(got_m[k], want_m[k]), k
+
+
+def test_errors_come_back_as_codes():
+    from nrc_amd import rc_ext
+    rc = rc_ext.RadianceCache(nrc_amd.hotdog_config(), 0)
+    with pytest.raises(rc_ext.RcError) as e:
+        rc.render_rays(nrc_amd.synthetic_rays(4).hot_fields(), None)        # nothing loaded
+    assert e.value.code == -3 and "missing weight" in str(e.value)
+    with pytest.raises(rc_ext.RcError) as e:
+        rc.load_weights({"params/Cache/Nope/kernel": np.zeros((2, 2), np.float32)})
+    assert e.value.code == -1

@@ -372,7 +372,8 @@ def test_secondary_rays_without_envmap_and_given_indices(rc):
 
 def test_primary_rays_with_forced_resampling(rc):
     """resample=True on primary rays (MaterialModel.resample_render, models.py:156-167): one shaded sample,
-    acc / distances from the unfiltered weights, bg = 1."""
+    acc / distances from the unfiltered weights, bg = 1.  White-noise tables: the Gumbel draw itself is checked
+    (>= 99 % equal picks); the values are compared with the oracle's picks handed over (next test holds 1e-4)."""
     from nrc_amd import rc_ext
     from oracle import cache_ref
     n = 256
@@ -383,12 +384,16 @@ def test_primary_rays_with_forced_resampling(rc):
                                   resample=True, gumbel=torch.from_numpy(g), want_grad_normals=False)
     out = rc.render_rays(rays.hot_fields(), {"gumbel": g}, rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_RESAMPLE)
     torch.cuda.synchronize()
-    same = rc.workspace("inds", np.int32)[:n] == ref["filtered_sampler_inds"][:, 0].numpy()
+    picks = ref["filtered_sampler_inds"][:, 0].numpy().astype(np.int32)
+    same = rc.workspace("inds", np.int32)[:n] == picks
     assert same.mean() >= 0.99
+    out = rc.render_rays(rays.hot_fields(), {"resample_inds": picks}, rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_RESAMPLE)
+    torch.cuda.synchronize()
+    assert np.array_equal(rc.workspace("inds", np.int32)[:n], picks)
     r = ref["render"]
     # ONE shaded sample per ray: the per-sample colour noise (1-ulp position differences amplified by the
     # random fine-level tables, ~3e-4 per sample) is not averaged over 32 samples here.
-    v, b = out["rgb"].cpu().numpy()[same], r["rgb"].numpy()[same]
+    v, b = out["rgb"].cpu().numpy(), r["rgb"].numpy()
     assert np.abs(v - b).max() <= 1e-3
     assert np.abs(v - b).mean() <= 2e-5
     assert np.abs(out["acc"].cpu().numpy() - r["acc"].numpy()).max() <= RGB_TOL
@@ -506,6 +511,153 @@ def test_material_stage_vs_oracle(rc_smooth, smooth):
         ds = ref["debug"]["specular"]
         rel = np.abs(smp[:, :16, 3] - ds["pdf"][..., 0].numpy()) / (ds["pdf"][..., 0].numpy() + 1.0)
         assert rel[same].max() <= 5e-2
+
+
+def test_forced_resampling_smooth_field_holds_1e4(rc_smooth):
+    """Same pass on the smooth field with the oracle's picks handed over (rc_randoms.resample_inds): every output
+    within the north-star 1e-4 L-inf (no percentile)."""
+    from nrc_amd import rc_ext
+    from oracle import cache_ref
+    n = 256
+    rays = nrc_amd.synthetic_rays(n)
+    rng = np.random.Generator(np.random.PCG64(3))
+    g = rng.gumbel(size=(n, 32)).astype(np.float32)
+    jit = common.jitters(n, seed=4)
+    ref = cache_ref.cache_forward(common.to_torch(common.weights_material_np(True)), nrc_amd.hotdog_config(),
+                                  common.rays_torch(rays), [torch.from_numpy(j) for j in jit], resample=True,
+                                  gumbel=torch.from_numpy(g), want_grad_normals=False)
+    picks = ref["filtered_sampler_inds"][:, 0].numpy().astype(np.int32)
+    mask = rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_RESAMPLE
+    drawn = rc_smooth.render_rays(rays.hot_fields(), {"jitter": jit, "gumbel": g}, mask, outputs=["rgb"])
+    torch.cuda.synchronize()
+    assert (rc_smooth.workspace("inds", np.int32)[:n] == picks).mean() >= 0.99
+    out = rc_smooth.render_rays(rays.hot_fields(), {"jitter": jit, "resample_inds": picks}, mask)
+    torch.cuda.synchronize()
+    r = ref["render"]
+    for k in ("rgb", "acc", "diffuse_rgb", "specular_rgb", "direct_rgb", "indirect_rgb", "albedo_rgb", "means",
+              "normals_pred", "distance_mean", "distance_median", "ray_dists"):
+        a = out[k].cpu().numpy()
+        d = np.abs(a - r[k].numpy().reshape(a.shape)).max()
+        assert d <= RGB_TOL, (k, d)
+
+
+MAT_ALL_KEYS = MAT_KEYS_3 + ("acc", "indirect_occ", "material_roughness", "material_metalness", "material_F_0",
+                             "ray_dists", "light_dists")
+
+
+def _material_with_picks(rc, rays, rnd, ref):
+    """rc_render_material with the reference run's categorical picks handed over (rc_material_randoms.resample_inds /
+    .sec_resample_inds): the two discrete steps per path can then not flip on a near-tie."""
+    rnd2 = dict(rnd, gumbel=None, spec_gumbel=None, diff_gumbel=None,
+                resample_inds=np.asarray(ref["inds"]).reshape(-1).astype(np.int32),
+                spec_resample_inds=np.asarray(ref["spec_inds"]).reshape(-1).astype(np.int32),
+                diff_resample_inds=np.asarray(ref["diff_inds"]).reshape(-1).astype(np.int32))
+    cres, mres = rc.render_material(rays.hot_fields(), rnd2)
+    torch.cuda.synchronize()
+    return cres, mres
+
+
+def test_material_stage_smooth_field_holds_1e4(rc_smooth):
+    """SURVEY a21-a23 at the north-star tolerance: with the oracle's picks handed over, `rgb` and every material key
+    agree with the fp32 oracle within 1e-4 L-inf on ALL rays (no percentile, no `same` mask), and so do the
+    importance-sampling intermediates (directions, pdfs, MIS weights)."""
+    from oracle import material_ref
+    cfg = nrc_amd.hotdog_config()
+    wn = common.weights_material_np(True)
+    n = 128
+    rays = nrc_amd.synthetic_rays(n, seed=77)
+    rnd = material_ref.draw_randoms(cfg, n, seed=3)
+    ref = material_ref.material_forward(common.to_torch(wn), cfg, common.rays_torch(rays), rnd)
+    picks = dict(inds=ref["inds"][:, 0].numpy(), spec_inds=ref["debug"]["specular"]["inds"].numpy(),
+                 diff_inds=ref["debug"]["diffuse"]["inds"].numpy())
+    # the Gumbel draws themselves: nearly all picks equal (a near-tie may flip)
+    rc_smooth.render_material(rays.hot_fields(), rnd)
+    torch.cuda.synchronize()
+    assert (rc_smooth.workspace("inds", np.int32)[:n] == picks["inds"]).mean() >= 0.98
+    cres, mres = _material_with_picks(rc_smooth, rays, rnd, picks)
+    rnd_p = dict(rnd, resample_inds=picks["inds"], spec_resample_inds=picks["spec_inds"], diff_resample_inds=picks["diff_inds"])
+    ref64 = material_ref.material_forward(common.to_torch(wn, torch.float64), cfg, common.rays_torch(rays, torch.float64), rnd_p)
+    assert np.array_equal(rc_smooth.workspace("inds", np.int32)[:n], picks["inds"])
+    assert np.array_equal(rc_smooth.workspace("s:inds", np.int32)[:n * 32],
+                          np.concatenate([picks["spec_inds"], picks["diff_inds"]]))
+    r = ref["render"]
+    for k in MAT_ALL_KEYS:
+        a = mres[k].cpu().numpy()
+        d = np.abs(a - r[k].numpy().reshape(a.shape)).max()
+        assert d <= RGB_TOL, (k, d)
+    assert np.abs(cres["rgb"].cpu().numpy() - r["cache_rgb"].numpy()).max() <= 1e-5
+    # importance sampling intermediates (a21): local directions, pdf, MIS weight
+    smp = rc_smooth.workspace("sec_samples").reshape(n, 32, 5)
+    d_n = float(np.abs(rc_smooth.workspace("m_nrm").reshape(n, 3) - ref64["filtered"]["normals_to_use"][:, 0].numpy()).max()) + 1e-6
+    assert d_n <= RGB_TOL
+    for blk, name in ((slice(0, 16), "specular"), (slice(16, 32), "diffuse")):
+        dd = ref["debug"][name]
+        assert np.abs(smp[:, blk, :3] - dd["local_lightdirs"].numpy()).max() <= RGB_TOL
+        pdf = dd["pdf"][..., 0].numpy()
+        # pdf = D cos / (4 wo.h) (render_utils.py:501-531).  wo.h is a cancelling dot product (0.012 from terms of 0.055
+        # on the worst sample: the view direction lies below the predicted normal's tangent plane), so the pdf inherits
+        # the shading normal's own fp32 error d_n -- asserted <= 1e-4 above, measured here -- as d_n / (wo.h) relative:
+        # the fp32 and fp64 ORACLES differ by 3.3e-2 where pdfs reach 1.8e3.  First-order bound with that measured d_n;
+        # the estimator divides a lobe carrying the same factor by this pdf, so the OUTPUTS hold the plain 1e-4.
+        d64 = ref64["debug"][name]
+        p64 = d64["pdf"][..., 0].numpy()
+        wi, wo = d64["local_lightdirs"].numpy(), d64["local_viewdirs"].numpy()
+        hv = wi + wo
+        hv = hv / np.maximum(np.linalg.norm(hv, axis=-1, keepdims=True), 1e-30)
+        wdoth = np.maximum(np.abs((wo * hv).sum(-1)), 1e-12)
+        cond = (4.0 * d_n / wdoth) if name == "specular" else 0.0
+        assert (np.abs(smp[:, blk, 3] - p64) <= RGB_TOL * (1.0 + p64) + p64 * cond).all()
+        assert np.abs(smp[:, blk, 4] - dd["weight"][..., 0].numpy()).max() <= RGB_TOL
+    sec_rgb = rc_smooth.workspace("sec_rgb").reshape(n * 32, 3)
+    ref_rgb = np.concatenate([ref["debug"]["specular"]["rgb"].numpy(), ref["debug"]["diffuse"]["rgb"].numpy()])
+    # per-secondary-ray radiance: ONE shaded sample times w / p of its pick (not an output: the outputs above average
+    # 16 of them per lobe and hold 1e-4)
+    assert np.abs(sec_rgb - ref_rgb).max() <= 5e-4
+    assert np.abs(sec_rgb - ref_rgb).mean() <= 1e-5
+
+
+def test_material_stage_golden_fp64(rc_smooth):
+    """tests/golden/hotdog_material_64_smooth.npz: the fp64 oracle's material stage (configs[2]) with its picks stored."""
+    from oracle import material_ref
+    g = np.load(os.path.join(GOLD, "hotdog_material_64_smooth.npz"))
+    n, rays_seed, rnd_seed = (int(v) for v in g["meta"])
+    cfg = nrc_amd.hotdog_config()
+    rays = nrc_amd.synthetic_rays(n, seed=rays_seed)
+    rnd = material_ref.draw_randoms(cfg, n, seed=rnd_seed)
+    picks = dict(inds=g["inds"], spec_inds=g["spec_inds"], diff_inds=g["diff_inds"])
+    cres, mres = _material_with_picks(rc_smooth, rays, rnd, picks)
+    for k in MAT_ALL_KEYS:
+        a = mres[k].cpu().numpy()
+        d = np.abs(a - g["render_" + k].reshape(a.shape)).max()
+        # colours at the north-star 1e-4; the geometry extras (unit normals from a normalised 3-vector of the MLP,
+        # positions, distances) at the 5e-4 this file gives them against float64
+        assert d <= (5e-4 if k in ("means", "normals_to_use", "ray_dists", "light_dists") else RGB_TOL), (k, d)
+    assert np.abs(cres["rgb"].cpu().numpy() - g["render_cache_rgb"]).max() <= 1e-5
+
+
+def test_material_stage_white_noise_with_picks(rc_smooth):
+    """White-noise tables with the picks handed over: every ray is compared (no `same` mask).  One-ulp differences of the
+    secondary sample positions are amplified by the 2048-cell random tables (the fp32 and fp64 oracles differ by 1e-3
+    here), so the bound stays statistical for this weight set; the 1e-4 claim is the smooth-field test above."""
+    from nrc_amd import rc_ext
+    from oracle import material_ref
+    cfg = nrc_amd.hotdog_config()
+    wn = common.weights_material_np(False)
+    rc = rc_ext.RadianceCache(cfg, 0)
+    rc.load_weights(wn)
+    n = 128
+    rays = nrc_amd.synthetic_rays(n, seed=77)
+    rnd = material_ref.draw_randoms(cfg, n, seed=3)
+    ref = material_ref.material_forward(common.to_torch(wn), cfg, common.rays_torch(rays), rnd)
+    picks = dict(inds=ref["inds"][:, 0].numpy(), spec_inds=ref["debug"]["specular"]["inds"].numpy(),
+                 diff_inds=ref["debug"]["diffuse"]["inds"].numpy())
+    cres, mres = _material_with_picks(rc, rays, rnd, picks)
+    r = ref["render"]
+    for k in MAT_ALL_KEYS:
+        a = mres[k].cpu().numpy()
+        d = np.abs(a - r[k].numpy().reshape(a.shape))
+        assert np.percentile(d, 95) <= 1e-3, (k, np.percentile(d, 95))
+        assert d.max() <= 2e-2, (k, d.max())
 
 
 def test_material_stage_reports_missing_weights(rc):
