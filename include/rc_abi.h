@@ -236,6 +236,19 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n_rays, const 
                        const rc_material_randoms* mrnd, int32_t num_secondary_samples,
                        const rc_outputs* cache_out, const rc_mat_outputs* mat_out, void* stream);
 
+/* -- the all-gather of the rendered pixels across the GPUs of one node: replaces
+ * jax.lax.all_gather(render_dict, axis_name="batch") inside render_eval_fn (internal/train_utils.py:3795-3815) for a
+ * host that drives RCCL itself (the Python host layer uses torch.distributed instead).
+ *   nccl_comm   an ncclComm_t of the caller (one rank per GPU, this handle's device), passed as void*
+ *   local       this rank's outputs, n_local rays each ([n_local,3] / [n_local] per slot)
+ *   full        [world * n_local, .] per slot; only slots non-NULL in BOTH structs are gathered
+ * Every rank must pass the same n_local and the same slot set (pad the last shard, as models.render_image pads its
+ * last chunk).  All slots go out as ONE grouped collective (ncclGroupStart/End) on `stream`, asynchronously.
+ * RCCL is resolved at run time from the library the process has already loaded (librccl.so, else RC_RCCL_LIBRARY):
+ * the comm and the calls then belong to the same RCCL instance.  RC_ERR_UNSUPPORTED when no RCCL can be found. */
+int rc_allgather_outputs(rc_handle* h, void* nccl_comm, const rc_outputs* local, int64_t n_local, const rc_outputs* full,
+                         void* stream);
+
 /* -- single operators on the path (used by the parity tests and by the roofline bench)
  * HashEncoding.__call__ incl. the contraction (internal/grid_utils.py:808-905, coord.py:37-69):
  * grid_id: 0..2 proposal density grids, 3 appearance, 4 material, 5 light.

@@ -4,7 +4,9 @@
 // per-batch workspace and the launch sequence that replaces BaseNeRFModel.__call__
 // (internal/models.py:657-774): 3 x [resample -> grid lookup -> density MLP] -> (categorical
 // resample) -> appearance grid -> cache shader -> volume compositing.
+#include <dlfcn.h>
 #include <math.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -1384,6 +1386,57 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_random
   RC_HIP(h, hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
   h->graphs.push_back(e);
   RC_HIP(h, hipGraphLaunch(e.exec, st));
+  return RC_OK;
+  RC_CATCH(h)
+}
+
+namespace {
+// RCCL entry points, resolved from the instance the process already has (torch ships its own librccl.so: linking a
+// second copy into this library would split the communicator state between two instances).
+struct RcclApi {
+  int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*group_start)() = nullptr;
+  int (*group_end)() = nullptr;
+  const char* (*error_string)(int) = nullptr;
+  bool tried = false;
+};
+RcclApi g_rccl;
+bool load_rccl() {
+  if (g_rccl.tried) return g_rccl.all_gather != nullptr;
+  g_rccl.tried = true;
+  void* lib = nullptr;
+  const char* env = getenv("RC_RCCL_LIBRARY");
+  if (env && *env) lib = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+  for (const char* nm : {"librccl.so", "librccl.so.1"}) if (!lib) lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+  for (const char* nm : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) if (!lib) lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return false;
+  g_rccl.all_gather = (decltype(g_rccl.all_gather))dlsym(lib, "ncclAllGather");
+  g_rccl.group_start = (decltype(g_rccl.group_start))dlsym(lib, "ncclGroupStart");
+  g_rccl.group_end = (decltype(g_rccl.group_end))dlsym(lib, "ncclGroupEnd");
+  g_rccl.error_string = (decltype(g_rccl.error_string))dlsym(lib, "ncclGetErrorString");
+  if (!g_rccl.group_start || !g_rccl.group_end) g_rccl.all_gather = nullptr;
+  return g_rccl.all_gather != nullptr;
+}
+const int kOutWidth[RC_OUT_COUNT] = {3, 1, 1, 1, 1, 1, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 1, 1, 3, 3};
+}  // namespace
+
+int rc_allgather_outputs(rc_handle* h, void* nccl_comm, const rc_outputs* local, int64_t n_local, const rc_outputs* full,
+                         void* stream_v) {
+  RC_TRY
+  if (!h) return RC_ERR_INVALID_ARG;
+  if (!nccl_comm || !local || !full) return fail(h, RC_ERR_INVALID_ARG, "rc_allgather_outputs: null argument");
+  if (n_local < 0) return fail(h, RC_ERR_INVALID_ARG, "rc_allgather_outputs: negative n_local");
+  if (n_local == 0) return RC_OK;
+  if (!load_rccl()) return fail(h, RC_ERR_UNSUPPORTED, "rc_allgather_outputs: no RCCL in this process (librccl.so / RC_RCCL_LIBRARY)");
+  RC_HIP(h, hipSetDevice(h->device));
+  const int kNcclFloat = 7;                                   // ncclFloat32 (rccl.h)
+  int rc = g_rccl.group_start();
+  for (int i = 0; i < RC_OUT_COUNT && rc == 0; ++i)
+    if (local->ptr[i] && full->ptr[i])
+      rc = g_rccl.all_gather(local->ptr[i], full->ptr[i], (size_t)n_local * kOutWidth[i], kNcclFloat, nccl_comm, (hipStream_t)stream_v);
+  const int rc_end = g_rccl.group_end();
+  if (rc == 0) rc = rc_end;
+  if (rc != 0) return fail(h, RC_ERR_HIP, std::string("rc_allgather_outputs: RCCL: ") + (g_rccl.error_string ? g_rccl.error_string(rc) : "error"));
   return RC_OK;
   RC_CATCH(h)
 }

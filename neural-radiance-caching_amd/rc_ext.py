@@ -148,7 +148,7 @@ EXPORTS = (
     "rc_hashgrid_lookup", "rc_sample_intervals", "rc_workspace_ptr", "rc_set_profiling", "rc_stage_count",
     "rc_stage_name", "rc_stage_times_ms", "rc_set_graph_mode", "rc_set_fused", "rc_render_material", "rc_set_transient", "rc_render_transient", "rc_cast_rays",
     "rc_prng_fill", "rc_density_grad_size", "rc_density_grad_layout", "rc_density_backward",
-    "rc_hashgrid_grad_layout", "rc_hashgrid_backward",
+    "rc_hashgrid_grad_layout", "rc_hashgrid_backward", "rc_allgather_outputs",
 )
 
 _LIB = None
@@ -220,6 +220,9 @@ def load_library():
     lib.rc_hashgrid_grad_layout.restype = C.c_int
     lib.rc_hashgrid_backward.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.rc_hashgrid_backward.restype = C.c_int
+    lib.rc_allgather_outputs.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(rc_outputs), C.c_int64, C.POINTER(rc_outputs),
+                                         C.c_void_p]
+    lib.rc_allgather_outputs.restype = C.c_int
     lib.rc_stage_count.restype = C.c_int
     lib.rc_stage_name.argtypes = [C.c_int32]
     lib.rc_stage_name.restype = C.c_char_p
@@ -660,6 +663,24 @@ class RadianceCache:
                                                 C.byref(mout), stream))
         self._keep = [held]
         return cres, mres
+
+    def allgather_outputs(self, nccl_comm: int, local: Dict[str, object], world: int):
+        """rc_allgather_outputs: gather this rank's outputs (dict name -> [n, .] cuda tensor, as render_rays returns) over
+        an RCCL communicator the caller owns (ncclComm_t as an integer address).  Returns name -> [world * n, .]."""
+        torch = self._torch
+        lo, fu, res = rc_outputs(), rc_outputs(), {}
+        n = None
+        for nm, t in local.items():
+            n = t.shape[0] if n is None else n
+            if t.shape[0] != n or not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError(f"output {nm}: expected contiguous float32 cuda tensors with one row count")
+            res[nm] = torch.empty((world * n,) + tuple(t.shape[1:]), dtype=torch.float32, device=t.device)
+            lo.ptr[OUTPUT_ID[nm]] = t.data_ptr()
+            fu.ptr[OUTPUT_ID[nm]] = res[nm].data_ptr()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.rc_allgather_outputs(self._h, C.c_void_p(nccl_comm), C.byref(lo), n, C.byref(fu), stream))
+        self._keep = [local]
+        return res
 
     # -- single operators ---------------------------------------------------------------------
     def cfg_grid(self, grid_id: int):

@@ -106,3 +106,43 @@ def test_errors_come_back_as_codes():
     with pytest.raises(rc_ext.RcError) as e:
         rc.load_weights({"params/Cache/Nope/kernel": np.zeros((2, 2), np.float32)})
     assert e.value.code == -1
+
+
+def _loaded_rccl():
+    """Path of the RCCL instance this process has mapped (torch's own copy), so that the communicator made below and
+    rc_allgather_outputs talk to the same library."""
+    import torch.distributed  # noqa: F401  (makes sure libtorch_hip and its RCCL are in)
+    for line in open("/proc/self/maps"):
+        if "librccl" in line:
+            return line.split()[-1]
+    return None
+
+
+def test_allgather_outputs_over_rccl_world_of_one():
+    """rc_allgather_outputs with a real RCCL communicator (one rank: this box has one GPU): the grouped collective runs
+    on the caller's stream and `full` equals `local` for every gathered slot; slots missing on one side are skipped."""
+    import ctypes as C
+    import os
+    path = _loaded_rccl() or "/opt/rocm/lib/librccl.so"
+    os.environ["RC_RCCL_LIBRARY"] = path
+    rccl = C.CDLL(path)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid, comm = UniqueId(), C.c_void_p()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        rc = common.make_rc()
+        n = 300
+        local = rc.render_rays(nrc_amd.synthetic_rays(n, seed=3).hot_fields(), None, outputs=["rgb", "acc", "normals_pred"])
+        full = rc.allgather_outputs(comm.value, local, world=1)
+        torch.cuda.synchronize()
+        for k in local:
+            assert torch.equal(full[k], local[k]), k
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
