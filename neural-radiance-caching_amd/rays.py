@@ -61,6 +61,26 @@ class Rays:
         return d
 
 
+@dataclasses.dataclass
+class Pixels:
+    """Mirror of utils.Pixels (internal/utils.py:126-139): integer pixel coordinates + per-ray metadata; what
+    create_render_fn's device function casts into Rays itself (internal/train_utils.py:3762-3792)."""
+    pix_x_int: _Array
+    pix_y_int: _Array
+    lossmult: _Array
+    near: _Array
+    far: _Array
+    cam_idx: _Array
+    light_idx: _Array
+    exposure_idx: Optional[_Array] = None
+    exposure_values: Optional[_Array] = None
+    device_idx: Optional[_Array] = None
+
+    def tree_map(self, fn) -> "Pixels":
+        return Pixels(**{f.name: (None if getattr(self, f.name) is None else fn(getattr(self, f.name)))
+                         for f in dataclasses.fields(self)})
+
+
 def _normalize(v):
     return v / np.linalg.norm(v, axis=-1, keepdims=True)
 

@@ -152,6 +152,7 @@ EXPORTS = (
 )
 
 _LIB = None
+_RAY_FIELDS = ("origins", "directions", "viewdirs", "near", "far", "lights", "normals")
 
 
 def library_path() -> str:
@@ -419,6 +420,66 @@ class RadianceCache:
         self._check(self.lib.rc_render_rays(self._h, C.byref(r), n, rnd_p, pass_mask, C.byref(cout), stream))
         self._keep = [held]   # keep inputs alive until the next call (async enqueue)
         return res
+
+    # -- lean per-chunk launch (models.render_image's hot loop at render_chunk_size = 1024) ------------
+    def output_plan(self, names, n: int):
+        """Layout of ONE flat float32 allocation holding the outputs `names` of an n-ray batch (every output starts on a
+        256-byte boundary): (total floats, {name: (offset, shape)}, [(rc_output_id, offset)])."""
+        offs, total, ids = {}, 0, []
+        for nm in names:
+            width = OUTPUTS[OUTPUT_ID[nm]][1]
+            offs[nm] = (total, (n, 3) if width == 3 else (n,))
+            ids.append((OUTPUT_ID[nm], total))
+            total += (n * width + 63) // 64 * 64
+        return max(total, 1), offs, ids
+
+    def render_chunk(self, rays: Dict[str, object], randoms, pass_mask: int, plan):
+        """rc_render_rays into one fresh flat buffer laid out by `plan` (output_plan).  The hot-loop variant of
+        render_rays: device-resident float32 ray fields are passed by pointer as they are (no reshape / copy), the
+        outputs are not wrapped into per-key tensors.  Returns (flat tensor, n)."""
+        torch = self._torch
+        r = rc_rays()
+        held = []
+        n = None
+        for k in _RAY_FIELDS:
+            v = rays.get(k)
+            if v is None:
+                continue
+            if not (isinstance(v, torch.Tensor) and v.is_cuda and v.dtype is torch.float32 and v.is_contiguous()):
+                v = self._dev(v)
+            held.append(v)
+            setattr(r, k, v.data_ptr())
+            if k == "near":
+                n = v.numel()
+        rnd_p = None
+        if randoms is not None:
+            rnd = rc_randoms()
+            jit = randoms.get("jitter")
+            if jit is not None:
+                for l, j in enumerate(jit):
+                    if j is not None:
+                        t = self._dev(j)
+                        held.append(t)
+                        rnd.jitter[l] = t.data_ptr()
+            if randoms.get("gumbel") is not None:
+                t = self._dev(randoms["gumbel"])
+                held.append(t)
+                rnd.gumbel = t.data_ptr()
+            if randoms.get("resample_inds") is not None:
+                t = self._dev(randoms["resample_inds"], torch.int32)
+                held.append(t)
+                rnd.resample_inds = t.data_ptr()
+            rnd_p = C.byref(rnd)
+        total, _, ids = plan
+        flat = torch.zeros(total, dtype=torch.float32, device=held[0].device)
+        base = flat.data_ptr()
+        cout = rc_outputs()
+        for oid, off in ids:
+            cout.ptr[oid] = base + 4 * off
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.rc_render_rays(self._h, C.byref(r), n, rnd_p, pass_mask, C.byref(cout), stream))
+        self._keep = held          # inputs stay alive until the next call (async enqueue)
+        return flat, n
 
     def _rays_struct(self, rays):
         r = rc_rays()

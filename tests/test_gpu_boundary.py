@@ -1,0 +1,228 @@
+"""The device-function boundary: create_render_fn's 8-argument render_eval_pfn called the way
+engine/trainer.py:822-832 calls it, the Pixels branch, render_image's device loop against its host loop, weight
+reloads, configs[3] at size on one GPU, the RCCL gather with one rank, checkpoints into rc_load_weights."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import common
+import nrc_amd
+from nrc_amd import model as M
+from nrc_amd import prng
+
+pytestmark = pytest.mark.gpu
+
+
+class _Dataset:
+    """What create_render_fn reads from the Trainer's dataset (internal/train_utils.py:3757-3760, 3805-3812)."""
+    camtype = "perspective"
+    mesh = env_map = env_map_pmf = env_map_pdf = env_map_dirs = env_map_w = env_map_h = albedo_ratio = None
+
+
+def _model(chunk=256, weights=None):
+    cfg = nrc_amd.hotdog_config(render_chunk_size=chunk)
+    m = M.Model(cfg, 0)
+    m.load_variables(weights if weights is not None else common.weights_np())
+    return cfg, m
+
+
+def _nested(flat):
+    tree = {}
+    for k, v in flat.items():
+        d = tree
+        parts = k.split("/")
+        for p in parts[:-1]:
+            d = d.setdefault(p, {})
+        d[parts[-1]] = v
+    return tree
+
+
+def test_render_eval_pfn_called_like_the_trainer():
+    """Trainer.render_primary_rays (engine/trainer.py:812-846): a closure over
+    render_eval_pfn(state.params, rng, train_frac, cameras_replicated, lights_replicated, rays, passes, resample) goes
+    through render_image with the per-device key array and num_repeats / compute_variance."""
+    cfg, m = _model(256)
+    # flax.jax_utils.replicate(state.params): every leaf with a leading [n_local_devices = 1] axis
+    params = _nested({k: np.asarray(v)[None] for k, v in common.weights_np().items()})
+    render_eval_pfn = M.create_render_fn(m, _Dataset(), mapping_fn=None)
+    train_frac, cameras, lights = 1.0, None, None
+
+    def render_fn(rng, rays, passes, resample):          # engine/trainer.py:821-832, verbatim shape
+        return render_eval_pfn(params, rng, train_frac, cameras, lights, rays, passes, resample)
+
+    rays = nrc_amd.synthetic_camera_rays(18, 20)          # 360 rays: 256 + 104 (edge padded)
+    render_rngs = prng.split(prng.PRNGKey(7), 1)          # random.split(rng, n_local_devices)
+    img, rng_out = M.render_image(render_fn, rng=render_rngs, rays=rays, config=cfg, passes=("cache",), resample=None,
+                                  num_repeats=2, compute_variance=True, verbose=False)
+    assert rng_out.shape == (1, 2) and rng_out.dtype == np.uint32 and not np.array_equal(rng_out, render_rngs)
+    assert img["rgb"].shape == (18, 20, 3) and img["rgb_variance"].shape == (18, 20, 3) and img["acc"].shape == (18, 20)
+    assert float(img["rgb_variance"].max()) > 0.0         # two repeats drew different jitter
+    # the first chunk, first repeat == model.apply with the key render_eval_fn derives (train_utils.py:3794)
+    apply_key, _ = prng.random_split(render_rngs[0])
+    flat = rays.tree_map(lambda r: np.asarray(r).reshape(360, -1)[:256])
+    one = m.apply(None, apply_key, flat)["render"]
+    one_fn, _ = render_eval_pfn(params, render_rngs, 1.0, None, None, M.shard(flat), ("cache",), None)
+    assert one_fn["rgb"].shape == (1, 1, 256, 3) and one_fn["acc"].shape == (1, 1, 256)
+    assert torch.equal(one_fn["rgb"][0, 0], one["rgb"])
+    assert set(one_fn.keys()) == set(one.keys())
+
+
+def test_device_loop_equals_host_loop():
+    """render_image keeps the chunk loop on the GPU when the render function comes from this package; a plain callable
+    gets the reference's host loop.  Same chunks, same padding, same Welford update: identical images, key by key."""
+    cfg, m = _model(512)
+    bound = M.bind_render_fn(M.create_render_fn(m))
+    plain = lambda rng, rays, passes, resample: bound(rng, rays, passes, resample)      # no .device: host loop
+    rays = nrc_amd.synthetic_camera_rays(37, 41)          # 1517 rays: 2 full chunks + 493
+    for repeats, key in ((1, None), (3, prng.PRNGKey(5))):
+        a, ra = M.render_image(bound, key, rays, cfg, ("cache",), verbose=False, num_repeats=repeats, compute_variance=True)
+        b, rb = M.render_image(plain, key, rays, cfg, ("cache",), verbose=False, num_repeats=repeats, compute_variance=True)
+        assert set(a) == set(b)
+        for k in a:
+            assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype, k
+            if repeats == 1:
+                assert np.array_equal(a[k], b[k]), k
+            else:                                         # the running mean is computed by torch there, numpy here
+                assert np.abs(a[k] - b[k]).max() <= 1e-6, k
+        assert (ra is None and rb is None) or np.array_equal(ra, rb)
+
+
+def test_pixels_branch_casts_on_the_device():
+    """render_eval_fn given utils.Pixels (internal/train_utils.py:3762-3792): cast_ray_batch on the device, two cameras
+    in one batch, per-pixel near / far / lossmult taken from the Pixels."""
+    cfg, m = _model(256)
+    pfn = M.create_render_fn(m, _Dataset())
+    W = H = 24
+    c2w = np.stack([np.array([[1, 0, 0, 0.1], [0, 1, 0, 0.2], [0, 0, 1, 4.0]], np.float32),
+                    np.array([[1, 0, 0, -0.3], [0, 1, 0, 0.1], [0, 0, 1, 3.8]], np.float32)])
+    p2c = np.stack([nrc_amd.get_pixtocam(30.0, W, H)] * 2).astype(np.float32)
+    cameras = (p2c[None], c2w[None], None, None, None)                 # replicated: leading device axis
+    lights = c2w[:, :, 3][None]
+    rng = np.random.default_rng(0)
+    n = 200
+    px, py = rng.integers(0, W, n), rng.integers(0, H, n)
+    cam_idx = (np.arange(n) % 2).astype(np.int32)
+    col = lambda v, dt=np.float32: np.full((1, n, 1), v, dt)
+    pixels = nrc_amd.Pixels(pix_x_int=px[None].astype(np.int32), pix_y_int=py[None].astype(np.int32), lossmult=col(1.0),
+                            near=col(2.0), far=col(6.0), cam_idx=cam_idx[None, :, None], light_idx=col(0, np.int32))
+    out, _ = pfn(None, None, 1.0, cameras, lights, pixels, ("cache",), None)
+    assert out["rgb"].shape == (1, 1, n, 3)
+    for c in (0, 1):
+        sel = np.nonzero(cam_idx == c)[0]
+        cam = nrc_amd.Camera(pixtocam=p2c[c], camtoworld=c2w[c], light=c2w[c][:, 3], near=2.0, far=6.0)
+        rays = nrc_amd.cast_ray_batch(m.rc, cam, px[sel].astype(np.int32), py[sel].astype(np.int32))
+        ref = m.apply(None, None, rays)["render"]
+        assert torch.equal(out["rgb"][0, 0][torch.from_numpy(sel).cuda()], ref["rgb"])
+    with pytest.raises(AssertionError):
+        M.create_render_fn(m, None)(None, None, 1.0, cameras, lights, pixels, ("cache",), None)      # camtype unknown
+
+
+def test_updated_variables_are_reloaded():
+    """The same variables tree handed over again is not re-uploaded; a replaced leaf or an in-place write into a torch
+    leaf is (no stale weights); `None` keeps what is loaded."""
+    cfg, m = _model(256)
+    rays = nrc_amd.synthetic_rays(64)
+    w = {k: torch.from_numpy(np.array(v)) for k, v in common.weights_np().items()}
+    a = m.apply(w, None, rays)["render"]["rgb"].clone()
+    loads = []
+    orig = m.rc.load_weights
+    m.rc.load_weights = lambda f: (loads.append(1), orig(f))[1]
+    assert torch.equal(m.apply(w, None, rays)["render"]["rgb"], a) and not loads
+    k = "params/Cache/Shader/irradiance_layer/bias"
+    w[k].add_(0.5)                                         # optimizer-style in-place update
+    b = m.apply(w, None, rays)["render"]["rgb"].clone()
+    assert len(loads) == 1 and not torch.equal(a, b)
+    w[k] = w[k] - 0.5                                      # functional update: a new leaf in the same container
+    c = m.apply(w, None, rays)["render"]["rgb"]
+    assert len(loads) == 2 and float((c - a).abs().max()) <= 1e-6
+    assert torch.equal(m.apply(None, None, rays)["render"]["rgb"], c) and len(loads) == 2
+
+
+def test_lego_800x800_on_one_gpu():
+    """BASELINE configs[3] at size on one GPU: the 800 x 800 image through render_image at the reference's documented
+    render_chunk_size = 1024 (625 chunks) and at 16 000; both bitwise equal to render_camera (rays cast on the device);
+    whole-image properties; the oracle on a strided subset at 1e-4."""
+    from oracle import cache_ref
+    H = W = 800
+    cfg, m = _model(1024)
+    o = np.array([0.0, -3.5, 2.0])
+    look = -o / np.linalg.norm(o)
+    right = np.cross(look, [0, 0, 1.0]); right /= np.linalg.norm(right)
+    up = np.cross(right, look)
+    c2w = np.concatenate([np.stack([right, up, -look], 1), o[:, None]], 1)
+    cam = nrc_amd.Camera(nrc_amd.get_pixtocam(1111.0, W, H), c2w, near=2.0, far=6.0)
+    drays = m.rc.cast_rays(cam, rect=(0, 0, W, H))
+    rays = drays.tree_map(lambda t: t.cpu().numpy())
+    fn = M.bind_render_fn(M.create_render_fn(m))
+    img, _ = M.render_image(fn, None, rays, cfg, ("cache",), verbose=False)
+    cfg16, _ = nrc_amd.hotdog_config(render_chunk_size=16000), None
+    img16, _ = M.render_image(fn, None, rays, cfg16, ("cache",), verbose=False)
+    for k in ("rgb", "acc", "distance_median", "normals_pred", "cache_rgb", "diffuse_rgb"):
+        assert img[k].shape[:2] == (H, W)
+        assert np.array_equal(img[k], img16[k]), k
+    cam_img = nrc_amd.render_camera(m, cam, H, W)
+    for k in ("rgb", "acc", "distance_median"):
+        assert np.array_equal(cam_img[k], img[k]), k
+    # properties over the whole image
+    assert np.isfinite(img["rgb"]).all() and (img["acc"] >= 0).all() and (img["acc"] <= 1 + 1e-5).all()
+    assert (img["distance_median"] >= 2.0 - 1e-4).all() and (img["distance_median"] <= 6.0 + 1e-4).all()
+    assert np.array_equal(img["rgb"], img["cache_rgb"]) and float(img["occ"].max()) == 0.0
+    assert np.abs(img["rgb"] - (img["diffuse_rgb"] + img["specular_rgb"] + (1 - np.minimum(img["acc"], 1))[..., None])).max() <= 2e-5
+    nrm = np.linalg.norm(img["normals_pred"], axis=-1)
+    assert (nrm <= img["acc"] + 1e-4).all()              # composited unit normals
+    # the oracle on a strided subset (every 251st ray: 2 550 rays)
+    idx = np.arange(0, H * W, 251)
+    flat = rays.tree_map(lambda r: np.asarray(r).reshape(H * W, -1)[idx])
+    ref = cache_ref.cache_forward(common.weights_torch(), cfg, common.rays_torch(flat), None, want_grad_normals=False)["render"]
+    d = np.abs(img["rgb"].reshape(-1, 3)[idx] - ref["rgb"].numpy())
+    assert d.max() <= 1e-4, d.max()
+    assert np.abs(img["acc"].reshape(-1)[idx] - ref["acc"].numpy()).max() <= 1e-4
+    mse = float(np.mean(d ** 2))
+    assert -10.0 * np.log10(max(mse, 1e-30)) >= 80.0
+
+
+def test_render_image_distributed_over_rccl_with_one_rank():
+    """render_image_distributed under the "nccl" backend (= RCCL) with a world of one: the collective code path that the
+    eight-GPU run takes executes here once; result == the single-process image; repeats are averaged before the gather."""
+    import socket
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        cfg, m = _model(1024)
+        rays = nrc_amd.synthetic_camera_rays(50, 60)
+        apply = lambda rng, r: m.apply(None, rng, r)
+        got = M.render_image_distributed(apply, None, rays, cfg, keys=("rgb", "acc", "distance_median", "normals_pred"))
+        torch.cuda.synchronize()
+        img, _ = M.render_image(M.bind_render_fn(M.create_render_fn(m)), None, rays, cfg, ("cache",), verbose=False)
+        for k in ("rgb", "acc", "distance_median", "normals_pred"):
+            assert np.array_equal(got[k].cpu().numpy(), img[k]), k
+        key = prng.PRNGKey(3)
+        rep = M.render_image_distributed(apply, key, rays, cfg, keys=("rgb", "acc"), num_repeats=3)
+        one = M.render_image_distributed(apply, key, rays, cfg, keys=("rgb", "acc"), num_repeats=1)
+        assert rep["rgb"].shape == (50, 60, 3) and not torch.equal(rep["rgb"], one["rgb"])
+        assert float((rep["rgb"] - one["rgb"]).abs().max()) < 0.5
+    finally:
+        dist.destroy_process_group()
+
+
+def test_checkpoint_round_trip_into_rc_load_weights(tmp_path):
+    """checkpoint.save_params -> load_params -> rc_load_weights renders bitwise what the direct load
+    renders (the Flax msgpack container, prefix restore included)."""
+    from nrc_amd import checkpoint
+    cfg, m = _model(256)
+    rays = nrc_amd.synthetic_rays(200, seed=4)
+    want = {k: v.clone() for k, v in m.apply(None, None, rays)["render"].items() if k in ("rgb", "acc", "normals_pred")}
+    path = checkpoint.save_params(common.weights_np(), str(tmp_path), step=25000)
+    assert os.path.basename(path) == "checkpoint_25000"
+    flat = checkpoint.load_params(str(tmp_path), prefixes=["params/Cache"])
+    assert set(flat) == {k for k in common.weights_np() if k.startswith("params/Cache")}
+    m2 = M.Model(cfg, 0)
+    m2.load_variables(flat)
+    got = m2.apply(None, None, rays)["render"]
+    for k, v in want.items():
+        assert torch.equal(got[k], v), k

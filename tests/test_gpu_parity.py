@@ -304,7 +304,7 @@ def test_render_image_matches_oracle_on_small_image():
     m = M.Model(cfg, 0)
     m.load_variables(common.weights_np())
     rays = nrc_amd.synthetic_camera_rays(18, 20)        # 360 rays -> chunks of 256 + 104 (padded)
-    img, _ = M.render_image(M.create_render_fn(m), None, rays, cfg, ("cache",), verbose=False)
+    img, _ = M.render_image(M.bind_render_fn(M.create_render_fn(m)), None, rays, cfg, ("cache",), verbose=False)
     assert img["rgb"].shape == (18, 20, 3) and img["acc"].shape == (18, 20) and img["rgb"].dtype == np.float32
     from oracle import cache_ref
     flat = rays.tree_map(lambda r: np.asarray(r).reshape(360, -1))
@@ -887,7 +887,7 @@ def test_transient_render_image_keys_and_shapes():
     H, W = 5, 6
     flat = nrc_amd.synthetic_transient_rays(H * W)
     rays = flat.tree_map(lambda r: np.asarray(r).reshape((H, W) + np.asarray(r).shape[1:]))
-    img, _ = M.render_image(M.create_render_fn(m), None, rays, cfg, ("cache",), verbose=False)
+    img, _ = M.render_image(M.bind_render_fn(M.create_render_fn(m)), None, rays, cfg, ("cache",), verbose=False)
     assert img["rgb"].shape == (H, W, 700, 3) and img["integrated_rgb"].shape == (H, W, 3) and img["acc"].shape == (H, W)
     assert "transient_direct_viz" in img and "transient_indirect_viz" in img
     assert not any(("transient" in k) and k not in ("transient_direct_viz", "transient_indirect_viz") for k in img)

@@ -172,7 +172,7 @@ def test_render_camera_with_key_draws_the_chunk_keys_of_render_image():
     from nrc_amd import Camera, get_pixtocam
     from nrc_amd.camera import render_camera
     from nrc_amd.config import hotdog_config
-    from nrc_amd.model import Model, create_render_fn, render_image
+    from nrc_amd.model import Model, bind_render_fn, create_render_fn, render_image
     cfg = hotdog_config(render_chunk_size=512)
     model = Model(cfg)
     model.load_variables(weights_np())
@@ -182,7 +182,7 @@ def test_render_camera_with_key_draws_the_chunk_keys_of_render_image():
     key = prng.PRNGKey(99)
     a = render_camera(model, cam, H, W, rows_per_chunk=16, rng=key)
     rays = model.rc.cast_rays(cam, rect=(0, 0, W, H)).tree_map(lambda t: t.cpu().numpy())
-    b, _ = render_image(create_render_fn(model), key, rays, cfg, ("cache",), verbose=False)
+    b, _ = render_image(bind_render_fn(create_render_fn(model)), key, rays, cfg, ("cache",), verbose=False)
     for k in ("rgb", "acc", "distance_median"):
         assert np.array_equal(a[k].reshape(-1), b[k].reshape(-1)), k
     d = render_camera(model, cam, H, W, rows_per_chunk=16, rng=None)
