@@ -17,7 +17,14 @@ packages exist in the build image (plain ModuleNotFoundError, no network), the
 reference ships no tests, golden vectors or fixtures for any file on this path
 (SURVEY.md §4, §8c), and it has no native sources to compile.  The oracle is
 therefore pinned only by (a) hand-computed known-answer tests of the risky
-conventions (tests/test_oracle_kat.py) and (b) fp64-vs-fp32 self-agreement.
+conventions (tests/test_oracle_kat.py), (b) independent library code where one
+exists (tests/test_oracle_independent.py), (c) fp64-vs-fp32 self-agreement and
+(d) a SECOND, independent restatement: oracle/spec_np.py (numpy float64,
+written from the reference lines in a separate pass, shares no code with the
+*_ref.py modules) which agrees with this torch oracle to float64 round-off on
+every fixture (tests/test_oracle_spec.py) and regenerates the goldens
+(tests/golden/make_golden.py --spec).  Two witnesses that agree rule out a
+transcription slip in one of them; they do not pin either to the reference.
 Randomness (jax.random / threefry) is not reproduced: every random quantity is
 an explicit input tensor.
 """

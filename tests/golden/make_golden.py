@@ -43,6 +43,26 @@ def cache_case(n_rays, jitter_seed, density_shift, name):
     print(name, {k: v.shape for k, v in list(d.items())[:4]}, "...")
 
 
+def cache_case_spec(n_rays, jitter_seed, density_shift, name, out_dir=None):
+    """The same fixture computed by the independent numpy float64 spec (oracle/spec_np.py) instead of the torch oracle:
+    `python tests/golden/make_golden.py --spec [dir]`.  The two agree to float64 round-off (tests/test_oracle_spec.py),
+    so after the float32 rounding of the stored arrays the files are equal up to the last bit of a few entries."""
+    from oracle import spec_np
+    rays = nrc_amd.synthetic_rays(n_rays)
+    jit = None if jitter_seed is None else common.jitters(n_rays, seed=jitter_seed)
+    out = spec_np.cache_forward(common.weights_np(density_shift), nrc_amd.hotdog_config(), rays.hot_fields(), jit)
+    d = {}
+    for l, lvl in enumerate(out["levels"]):
+        for k in ("sdist", "tdist", "density", "weights"):
+            d[f"l{l}_{k}"] = lvl[k].astype(np.float32)
+    d["shade_rgb"] = out["per_sample"]["rgb"].astype(np.float32)
+    for k, v in out["render"].items():
+        d["render_" + k] = v.astype(np.float32)
+    d["meta"] = np.array([n_rays, -1 if jitter_seed is None else jitter_seed, density_shift], dtype=np.float64)
+    np.savez_compressed(os.path.join(out_dir or HERE, name), **d)
+    print("[spec]", name)
+
+
 def operator_cases():
     cfg = nrc_amd.hotdog_config()
     wt = common.weights_torch(dtype=F64)
@@ -106,6 +126,12 @@ def material_case(n_rays, rays_seed, rnd_seed, name):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--spec":          # the cache fixtures from the independent numpy spec
+        out_dir = sys.argv[2] if len(sys.argv) > 2 else None
+        cache_case_spec(256, None, 0.0, "hotdog_cache_256_det.npz", out_dir)
+        cache_case_spec(256, 7, 0.0, "hotdog_cache_256_jit.npz", out_dir)
+        cache_case_spec(64, 11, 4.0, "hotdog_cache_64_shell.npz", out_dir)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "material":        # only the material fixture
         material_case(64, 78, 5, "hotdog_material_64_smooth.npz")
         sys.exit(0)
