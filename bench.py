@@ -11,9 +11,15 @@ With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank rend
 the rendered pixels are all-gathered over RCCL once at the end, outside the per-step loop, exactly
 as the image renderer does once per image.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the cache shader, fp32 MFMA
-bound); its duration comes from HIP events recorded on the launch stream inside the timed region.
-`hashgrid` reports the achieved algorithmic GB/s of the four grid-lookup kernels the same way.
+The timed loop cycles through 64 different resident ray batches (no step re-renders the rays of the step before).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_cache_fused, fp32 MFMA
+bound); its duration comes from HIP events recorded on the launch stream inside the timed region; `traffic` is read
+from the PMC file tools/prof_round.sh leaves under profiles/ and is null when that file belongs to other kernel sources.
+`hashgrid` reports the achieved algorithmic GB/s of the grid lookups twice: of the four stand-alone kernels (measured
+here, separate pass on the launch-per-stage plan) and of the gather phases inside the fused kernel (in-kernel stamps
+of a diagnostic build, profiles/, same staleness rule).  `parity` is max |rgb - oracle| and the PSNR of the first batch.
+`image` times BASELINE configs[3]: the 800 x 800 image, rays sharded over the ranks (strong scaling), one all-gather.
 `cpu_baseline` times the CPU oracle (a torch fp32 restatement of the reference path, kind "port":
 the JAX reference cannot run here) on a bounded sample of the same workload.
 """
@@ -40,8 +46,21 @@ FUSED_FLOP_PER_RAY = sum(s * f for s, f in zip(SAMPLES, DENSITY_FLOP_PER_SAMPLE)
 assert FUSED_FLOP_PER_RAY == 9703424
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
-# per-launch FETCH_SIZE + WRITE_SIZE (KiB) of the dominant kernel, profiles/r01_pmc_summary.txt
-PMC_KIB = {"fused": 113985.5 + 248.0, "shader": 8656.1 + 1920.0}
+N_BATCHES = 64                           # distinct ray batches the timed loop cycles through
+PROFILES = os.path.join(ROOT, "profiles")
+
+
+def measured_file(name, source_hash):
+    """A measurement kept under profiles/ (written by tools/prof_round.sh / tools/gpu_stamps_fused.py on a GPU box):
+    returned only when it was taken on the kernel sources this run uses, else None (stale numbers are not reported)."""
+    path = os.path.join(PROFILES, name)
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None, f"profiles/{name} missing"
+    if d.get("source_hash") != source_hash:
+        return None, f"profiles/{name} was measured on other kernel sources ({d.get('source_hash')} != {source_hash})"
+    return d, f"profiles/{name}"
 
 
 def host_cpu_share(cap=16):
@@ -212,6 +231,50 @@ def train_backward_line(local_rank, dev, n_rays=1024, steps=20, warmup=3):
             "note": "scatter into the tables is bound by the memory-side atomic request rate (DESIGN.md 4.4)"}
 
 
+def image_line(rc_model, cfg, dev, world, rank, dist, reps=3):
+    """BASELINE configs[3]: the 800 x 800 image (640 000 rays) rendered by render_image_distributed -- every rank its
+    contiguous share of the rays (cast on the device beforehand: inputs resident in HBM), one all-gather of the consumed
+    keys per image (RCCL when world > 1).  Strong scaling: the image is fixed, the ranks split it.  Max over ranks."""
+    import numpy as np
+    import torch
+
+    import nrc_amd
+    from nrc_amd import model as M
+
+    H = W = 800
+    o = np.array([0.0, -3.5, 2.0])
+    look = -o / np.linalg.norm(o)
+    right = np.cross(look, [0, 0, 1.0]); right /= np.linalg.norm(right)
+    up = np.cross(right, look)
+    c2w = np.concatenate([np.stack([right, up, -look], 1), o[:, None]], 1)
+    cam = nrc_amd.Camera(nrc_amd.get_pixtocam(1111.0, W, H), c2w, near=2.0, far=6.0)
+    rays = rc_model.rc.cast_rays(cam, rect=(0, 0, W, H))
+    icfg = nrc_amd.hotdog_config(render_chunk_size=16384)
+    apply = lambda rng, r: rc_model.apply(None, rng, r)
+    keys = ("rgb", "acc", "distance_median", "normals_pred")
+    times = []
+    for i in range(reps + 1):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        img = M.render_image_distributed(apply, None, rays, icfg, keys=keys)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if i:
+            times.append(dt)
+    ms = sorted(times)[len(times) // 2] * 1e3
+    return {"workload": "lego/hotdog-architecture 800x800 image, rays sharded over the ranks, one all-gather of "
+                        "rgb+acc+distance_median+normals_pred per image (configs[3])",
+            "scaling": "strong", "n_gpus": world, "ms_per_image": ms, "rays_per_s": H * W / (ms * 1e-3),
+            "render_chunk_size": icfg.render_chunk_size, "acc_mean": float(img["acc"].mean()),
+            "collective": "all_gather_into_tensor over RCCL" if world > 1 else "none (one rank)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,6 +287,8 @@ def main():
                     help="skip the secondary measurement of the material stage (configs[2])")
     ap.add_argument("--no-train", action="store_true",
                     help="skip the secondary measurement of the density fields' backward pass (SURVEY 8(f) rank 4)")
+    ap.add_argument("--no-image", action="store_true",
+                    help="skip the 800x800 image line (configs[3], strong scaling over the ranks)")
     ap.add_argument("--graph-mode", type=int, default=2, help="0 eager, 1 lazy hipGraph, 2 hipGraph at once")
     ap.add_argument("--plan", choices=("fused", "staged"), default="fused",
                     help="fused: one launch per batch (rc_set_fused 1, default); staged: one launch per stage")
@@ -245,6 +310,7 @@ def main():
     import torch
 
     import nrc_amd
+    from nrc_amd import model as M
     from nrc_amd import rc_ext
     from nrc_amd.model import _CACHE_DEVICE_KEYS
 
@@ -265,16 +331,24 @@ def main():
 
     cfg = nrc_amd.hotdog_config()
     weights = nrc_amd.synthetic_weights(cfg)
-    rc = rc_ext.RadianceCache(cfg, local_rank)
-    rc.load_weights(weights)
+    model = M.Model(cfg, local_rank)
+    model.load_variables(weights)
+    rc = model.rc
     rc.set_graph_mode(args.graph_mode)
     fused = args.plan == "fused"
     rc.set_fused(fused)
-    rays_np = nrc_amd.synthetic_rays(RAYS_PER_BATCH, seed=20200823 + rank)
-    rays = {k: torch.from_numpy(np.asarray(v)).to(dev).contiguous() for k, v in rays_np.hot_fields().items()}
-    rays["near"] = rays["near"].reshape(-1)
-    rays["far"] = rays["far"].reshape(-1)
-    rays.pop("lossmult", None)
+
+    def batch(seed):
+        r = nrc_amd.synthetic_rays(RAYS_PER_BATCH, seed=seed)
+        f = {k: torch.from_numpy(np.asarray(v)).to(dev).contiguous() for k, v in r.hot_fields().items()}
+        f["near"], f["far"] = f["near"].reshape(-1), f["far"].reshape(-1)
+        f.pop("lossmult", None)
+        return f
+
+    # N_BATCHES different ray batches per rank, all resident in HBM: step i renders batch i % N_BATCHES, so no step
+    # finds the lines its gathers touch warm from an identical step before it
+    batches = [batch(20200823 + 1000 * rank + b) for b in range(N_BATCHES)]
+    rays = batches[0]
 
     nstr = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstr)] if nstr > 1 else [torch.cuda.current_stream(dev)]
@@ -284,10 +358,11 @@ def main():
             outs.append(rc.render_rays(rays, None, outputs=_CACHE_DEVICE_KEYS))
     torch.cuda.synchronize()
     out = outs[0]
+    first = {k: v.clone() for k, v in out.items()}          # batch 0, for the parity block
 
     def step(i):
         with torch.cuda.stream(streams[i % nstr]):
-            rc.render_rays(rays, None, out=outs[i % nstr])
+            rc.render_rays(batches[i % N_BATCHES], None, out=outs[i % nstr])
 
     # Timed region: two HIP events around the dominant kernel, on every 8th step by default (an event record costs
     # ~1.3 us of stream time; the last 16 sampled launches, spread over the last 128 steps, are averaged).  The full
@@ -318,19 +393,32 @@ def main():
         gathered = torch.empty((world * pix.shape[0], 4), device=dev)
         dist.all_gather(list(gathered.chunk(world)), pix)
     sh_ms = rc.stage_times_ms()["shader"] if args.profile_mode else float("nan")
+    rc.set_profiling(0)
+    # configs[3]: every rank takes part (collective inside); before the single-rank extras
+    image = None
+    if not args.no_image:
+        rc.set_fused(True)
+        try:
+            image = image_line(model, cfg, dev, world, rank, dist)
+        except Exception as e:      # noqa: BLE001
+            print(f"[bench] image line failed: {e!r}", file=sys.stderr, flush=True)
+            image = {"error": repr(e)}
     # separate pass: every stage bracketed by events (not part of `value`)
     rc.set_fused(False)
     rc.render_rays(rays, None, out=out)
     rc.set_profiling(1)
-    for _ in range(16):
-        rc.render_rays(rays, None, out=out)      # single stream: undisturbed per-stage times
+    for i in range(16):
+        rc.render_rays(batches[i % N_BATCHES], None, out=out)      # single stream: undisturbed per-stage times
     torch.cuda.synchronize()
     stage = rc.stage_times_ms()
+    rc.set_profiling(0)
+    rc.set_fused(fused)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
+    src_hash = rc_ext.source_hash()
     rays_total = RAYS_PER_BATCH * world * args.steps
     value = rays_total / elapsed
     flops = (FUSED_FLOP_PER_RAY if fused else SHADER_FLOP_PER_SAMPLE * SHADED_SAMPLES) * RAYS_PER_BATCH
@@ -338,6 +426,15 @@ def main():
     grid_ms = sum(stage[k] for k in GRID_BYTES)
     grid_bytes = sum(GRID_BYTES.values()) * RAYS_PER_BATCH
     grid_gbs = grid_bytes / (grid_ms * 1e-3) / 1e9
+    pmc, pmc_src = measured_file("pmc_k_cache_fused.json" if fused else "pmc_k_cache_shader.json", src_hash)
+    stamps, stamps_src = measured_file("fused_phase_stamps.json", src_hash)
+    in_fused = None
+    if stamps is not None:
+        g_us = sum(stamps["phases_us"][k] for k in ("gather0", "gather1", "gather2"))
+        in_fused = {"what": "gather phases inside k_cache_fused (in-kernel s_memtime stamps of the diagnostic build, "
+                            "median over the 1024 rays; the level-2 phase looks the density and the appearance grid up together)",
+                    "achieved": grid_bytes / (g_us * 1e-6) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": grid_bytes / (g_us * 1e-6) / 1e9 / PEAK_HBM_GBS, "sum_phase_us": g_us}
     res = {
         "metric": "rays/sec (1024-ray batch, 64+64 proposal + 32 shaded samples/ray), hotdog cache forward",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -345,22 +442,28 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "hotdog cache render 1024 rays x (64,64,32) samples, cache-only passes, "
                                "synthetic rays + synthetic weights (configs[1])",
-                   "rays_per_batch_per_gpu": RAYS_PER_BATCH, "parallelism": f"ray-sharded x{world}",
+                   "rays_per_batch_per_gpu": RAYS_PER_BATCH, "distinct_batches_cycled": N_BATCHES,
+                   "parallelism": f"ray-sharded x{world}",
                    "launch": "eager" if (args.profile_mode or args.graph_mode == 0 or fused) else "hipGraph",
                    "batches_in_flight": nstr,
-                   "kernel_plan": "fused: 1 launch per batch, 1 wavefront per ray" if fused else "staged: 13 launches per batch"},
+                   "kernel_plan": "fused: 1 launch per batch, 1 wavefront per ray" if fused else "staged: 13 launches per batch",
+                   "kernel_source_hash": src_hash},
         "roofline": {"kernel": "k_cache_fused" if fused else "k_cache_shader", "bound": "mfma", "achieved": achieved_tf,
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
-                     # HBM-side bytes per launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE +
-                     # WRITE_SIZE in KiB, uncorrected: random 4/16-byte gathers); not re-measured here
-                     "traffic": (PMC_KIB["fused"] if fused else PMC_KIB["shader"]) * 1024,
-                     "traffic_source": "profiles/r01_pmc_summary.txt",
+                     # HBM-side bytes per launch: FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes (KiB as
+                     # reported: random 4/16-byte gathers, the x2 correction for wide streaming reads does not apply);
+                     # null when the file under profiles/ was not measured on these kernel sources
+                     "traffic": None if pmc is None else (pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024,
+                     "traffic_source": pmc_src,
                      "avg_launch_ms": sh_ms,
                      "algorithmic_flop_per_launch": flops},
-        "hashgrid": {"kernels": "k_hashgrid_fwd x4 (grid0, grid1, grid2, grid_app)", "bound": "hbm",
+        "hashgrid": {"kernels": "k_hashgrid_fwd x4 (grid0, grid1, grid2, grid_app), stand-alone: launch-per-stage plan, "
+                                "separate pass (NOT the path `value` times)", "bound": "hbm",
                      "achieved": grid_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": grid_gbs / PEAK_HBM_GBS,
-                     "sum_launch_ms": grid_ms, "algorithmic_bytes_per_batch": grid_bytes},
+                     "sum_launch_ms": grid_ms, "algorithmic_bytes_per_batch": grid_bytes,
+                     "in_fused_kernel": in_fused, "in_fused_source": stamps_src},
         "stage_ms_separate_pass_staged_plan": stage,
+        "image": image,
     }
     # the secondary lines must never cost the headline line: a failure is reported in place of the numbers
     def secondary(name, fn, *fargs):
@@ -381,12 +484,35 @@ def main():
         res["cpu_baseline"] = secondary("cpu_baseline", cpu_baseline, cfg, weights, RAYS_PER_BATCH)
     else:
         res["cpu_baseline"] = None
+    # parity of what was timed: batch 0 of the timed loop against the fp32 oracle (256 of its rays: seconds on the host)
+    res["parity"] = secondary("parity", parity_block, cfg, weights, rank, first)
     sys.stdout.flush()
     os.dup2(json_fd, 1)
     os.close(json_fd)
     print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def parity_block(cfg, weights_np, rank, first, n_check=256):
+    """max |rgb - oracle| and PSNR = -10 log10(mse) (internal/utils.py:50) of the first `n_check` rays of batch 0."""
+    import numpy as np
+    import torch
+
+    import nrc_amd
+    from oracle import cache_ref
+
+    torch.set_num_threads(host_cpu_share())
+    rays = nrc_amd.synthetic_rays(RAYS_PER_BATCH, seed=20200823 + 1000 * rank)
+    rt = {k: torch.from_numpy(np.asarray(v)[:n_check]) for k, v in rays.hot_fields().items()}
+    wt = {k: torch.from_numpy(v) for k, v in weights_np.items()}
+    ref = cache_ref.cache_forward(wt, cfg, rt, None, want_grad_normals=False)["render"]
+    d = (first["rgb"][:n_check].cpu() - ref["rgb"]).abs()
+    mse = float((d ** 2).mean())
+    return {"against": f"torch fp32 oracle on the first {n_check} rays of batch 0 (parity unpinned: the oracle is a "
+                       "restatement, see oracle/__init__.py)",
+            "max_abs_rgb": float(d.max()), "psnr_db": float(-10.0 * np.log10(max(mse, 1e-30))),
+            "max_abs_acc": float((first["acc"][:n_check].cpu() - ref["acc"]).abs().max()), "tolerance": 1e-4}
 
 
 if __name__ == "__main__":

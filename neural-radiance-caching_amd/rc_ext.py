@@ -160,6 +160,21 @@ def library_path() -> str:
     return os.environ.get("RC_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librc_hip.so")
 
 
+def source_hash() -> str:
+    """sha256 over the kernel / ABI sources the library is built from: what measurement files kept under profiles/
+    (PMC traffic, in-kernel phase stamps) are tagged with, so that a bench run can tell a stale file from a current one."""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(here, "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".inc")))
+    files.append(os.path.join(os.path.dirname(here), "include", "rc_abi.h"))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_library():
     """dlopen librc_hip.so.  Raises (never falls back) when it has not been built."""
     global _LIB

@@ -31,4 +31,12 @@ print("clock GHz", ghz)
 for i, nm in enumerate(names[:11]):
     print(f"  {nm:12s} median {np.median(seg[:, i]):9.0f} cyc = {np.median(seg[:, i]) / ghz / 1e3:7.2f} us   p95 {np.percentile(seg[:, i], 95) / ghz / 1e3:7.2f} us")
 print("total median us", np.median(tot) / ghz / 1e3, "kernel span us", (d[:, 15].max() - d[:, 14].min()) / 100.0, "start skew us", (d[:, 14].max() - d[:, 14].min()) / 100.0)
+if len(sys.argv) > 3:      # JSON for profiles/fused_phase_stamps.json (bench.py's hashgrid.in_fused_kernel block)
+    import json
+    json.dump({"source_hash": rc_ext.source_hash(), "n_rays": n, "clock_ghz": float(ghz),
+               "phases_us": {nm.split("+")[0].split("(")[0] if nm.startswith("gather") else nm: float(np.median(seg[:, i]) / ghz / 1e3) for i, nm in enumerate(names)},
+               "total_us": float(np.median(tot) / ghz / 1e3),
+               "how": "tools/gpu_stamps_fused.py on the -DRC_STAMPS build (make diag): s_memtime at the phase boundaries of "
+                      "k_cache_fused, median over the rays of one 1024-ray batch; the stamps add ~3 % to the kernel"},
+              open(sys.argv[3], "w"), indent=1)
 print("gather0 detail us: pos+contract", np.median(d[:, 12] - d[:, 1]) / ghz / 1e3, "issue", np.median(d[:, 13] - d[:, 12]) / ghz / 1e3, "wait+combine", np.median(d[:, 2] - d[:, 13]) / ghz / 1e3)
