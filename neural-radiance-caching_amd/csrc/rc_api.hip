@@ -975,7 +975,7 @@ int rc_set_profiling(rc_handle* h, int32_t enabled) {
 int rc_set_fused(rc_handle* h, int32_t mode) {
   RC_TRY
   if (!h) return RC_ERR_INVALID_ARG;
-  if (mode < 0 || mode > 1) return fail(h, RC_ERR_INVALID_ARG, "rc_set_fused: mode must be 0 or 1");
+  if (mode < 0 || mode > 2) return fail(h, RC_ERR_INVALID_ARG, "rc_set_fused: mode must be 0, 1 or 2");
   if (mode != h->fused_mode) drop_graphs(h);
   h->fused_mode = mode;
   return RC_OK;
@@ -1156,6 +1156,17 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
 
     stage_mark(h, slot, ST_GRID0 + 3 * l, st);
     const bool want_grad = (l == NL - 1) && (A.out.ptr[RC_OUT_NORMALS] != nullptr || A.force_grad);
+    // only the density of this level's samples is consumed behind it (proposal levels; the last level on the lean
+    // resampling pass): grid lookup + density MLP as ONE launch, weights resident in LDS (rc_level.hip)
+    if (h->fused_mode != 0 && !h->profiling && rc_level_supported(h->grids[l].dev) && !want_grad &&
+        (l < NL - 1 || (lean && !A.tout))) {
+      RcLevelArgs la{};
+      la.grid = &h->grids[l].dev; la.means = W(h, "means" + L); la.n = np; la.wstream = h->packs["dens_" + L].p;
+      la.density_bias = c.density_bias; la.contract_radius = c.contract_radius; la.density = W(h, "density" + L);
+      stage_mark(h, slot, ST_MLP0 + 3 * l, st);
+      rc_launch_level(la, st);
+      continue;
+    }
     rc_launch_hashgrid(h->grids[l].dev, W(h, "means" + L), 1, np, W(h, "feat" + L), 1, np, c.contract_radius,
                        want_grad ? W(h, "jac") : nullptr, st);
 
@@ -1302,7 +1313,7 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_random
   }
   if (secondary && !(pass_mask & RC_PASS_NO_ENVMAP) && !h->have_envmap)
     return fail(h, RC_ERR_MISSING_WEIGHT, "missing weight: params/Cache/EnvMap/* (secondary rays composite the model-level EnvMap)");
-  const bool fused = h->fused_mode != 0 && h->fused_ok && pass_mask == RC_PASS_CACHE;
+  const bool fused = h->fused_mode == 1 && h->fused_ok && pass_mask == RC_PASS_CACHE;
   // one workspace set per caller stream (up to 4): calls on different streams do not share buffers.  The fused kernel
   // keeps every intermediate on chip: no workspace, no set.
   const int ws_slot = fused ? 0 : ws_pick(h, st);

@@ -188,7 +188,9 @@ __device__ __forceinline__ void park(const f32x16 (&acc)[NT], float* act, int ba
 // w_o[feature(t, r, half-wave)], then one fragment per output holding the bias on every lane.  PT point-tiles share
 // each weight read.  `keep` (optional, KEEP) returns the weights of output 0 (the backward pass of the analytic
 // normals starts from them).  Two partial sums per output (even / odd registers), the two half-waves added last.
-template <int PT, int NT, int NO, int FBASE, int NF, bool KEEP = false, int W = kWaves>
+// NOB: outputs the layer was packed with (the bias fragments sit behind NOB * NT * 16 weight fragments); a caller
+// that needs only the first NO < NOB outputs skips the rest.  CH: fragments per ring chunk (see ws_issue).
+template <int PT, int NT, int NO, int FBASE, int NF, bool KEEP = false, int W = kWaves, int NOB = NO, int CH = kChunk>
 __device__ __forceinline__ void dot_out(const WStream& w, const f32x16 (&hid)[PT][NT], float (&out)[PT][NO],
                                         float (&keep)[KEEP ? NT * 16 : 1]) {
   float part[PT][NO][2];
@@ -202,14 +204,14 @@ __device__ __forceinline__ void dot_out(const WStream& w, const f32x16 (&hid)[PT
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float wv = ws_read<NF, W>(w, FBASE + (o * NT + t) * 16 + r);
+        const float wv = ws_read<NF, W, CH>(w, FBASE + (o * NT + t) * 16 + r);
         if constexpr (KEEP) { if (o == 0) keep[t * 16 + r] = wv; }
 #pragma unroll
         for (int p = 0; p < PT; ++p) part[p][o][r & 1] = __builtin_fmaf(fmaxf(hid[p][t][r], 0.0f), wv, part[p][o][r & 1]);
       }
 #pragma unroll
   for (int o = 0; o < NO; ++o) {
-    const float bias = ws_read<NF, W>(w, FBASE + NO * NT * 16 + o);
+    const float bias = ws_read<NF, W, CH>(w, FBASE + NOB * NT * 16 + o);
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
       float sum = part[p][o][0] + part[p][o][1];
@@ -218,12 +220,12 @@ __device__ __forceinline__ void dot_out(const WStream& w, const f32x16 (&hid)[PT
     }
   }
 }
-template <int NT, int NO, int FBASE, int NF, bool KEEP = false, int W = kWaves>
+template <int NT, int NO, int FBASE, int NF, bool KEEP = false, int W = kWaves, int NOB = NO, int CH = kChunk>
 __device__ __forceinline__ void dot_out1(const WStream& w, const f32x16 (&hid)[NT], float (&out)[NO],
                                          float (&keep)[KEEP ? NT * 16 : 1]) {
   const f32x16 (&h1)[1][NT] = reinterpret_cast<const f32x16 (&)[1][NT]>(hid);
   float (&o1)[1][NO] = reinterpret_cast<float (&)[1][NO]>(out);
-  dot_out<1, NT, NO, FBASE, NF, KEEP, W>(w, h1, o1, keep);
+  dot_out<1, NT, NO, FBASE, NF, KEEP, W, NOB, CH>(w, h1, o1, keep);
 }
 
 __device__ __forceinline__ float softplus(float x) {

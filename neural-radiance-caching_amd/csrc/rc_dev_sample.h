@@ -17,6 +17,8 @@ __device__ __forceinline__ void lds_sync() {
   }
 }
 
+__device__ __forceinline__ void lds_sync_wave() { lds_sync<false>(); }
+
 constexpr int kWavesPerBlock = 4;
 constexpr int kMaxBins = 64;          // P, S <= 64
 constexpr int kSlots = kMaxBins + 1;  // fence posts

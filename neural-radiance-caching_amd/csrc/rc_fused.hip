@@ -142,7 +142,12 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
   auto resample = [&](int level, int P, int S, float logit, const float* s_prev) {
     const bool hasj = a.jitter[level] != nullptr;
     const float jit = hasj ? a.jitter[level][ray] : 0.0f;
+#if defined(RC_ABL) && RC_ABL == 14
+    for (int e2 = lane; e2 <= S; e2 += 64) s_out[e2] = (float)e2 / (float)S + 1e-9f * logit;
+    lds_sync<false>();
+#else
     sample_intervals_wave<false>(logit, P, S, a.us[level], hasj, jit, s_prev, s_cw, s_c, s_v, s_out, lane);
+#endif
     if constexpr (FRONT) {
       if (a.use_raydist) {      // TransientNeRFModel samples its primary rays in power-ladder distance (models.py:122, 183-191)
         const float s_near = power_ladder(near, a.raydist_p, a.raydist_premult), s_far = power_ladder(far, a.raydist_p, a.raydist_premult);
@@ -182,6 +187,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
     float f[6];
     {
       const float ux = unit_box(a.grid[0].bbox, cx), uy = unit_box(a.grid[0].bbox, cy), uz = unit_box(a.grid[0].bbox, cz);
+#if defined(RC_ABL) && RC_ABL == 11
+      for (int l = 0; l < 6; ++l) f[l] = ux * (float)l + uy - uz;
+#else
       Corners<1> C[6];          // all 48 corner loads in flight before the first combine
       RC_FSTAMP(12);
 #pragma unroll
@@ -194,9 +202,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
         grid_combine<1, false>(C[l], v, jd);
         f[l] = v[0] * a.grid[0].precondition;
       }
+#endif
     }
     RC_FSTAMP(2);
+#if defined(RC_ABL) && RC_ABL == 13
+    const float raw = f[0] + f[5];
+#else
     const float raw = density_level64<6, F_L0, NF>(ws, act_wave, lane, f);
+#endif
     w = alpha_weight(density_of(raw, cx, cy, cz, a.grid[0].bbox), t0, t1, dnorm, true, lane);
   }
   RC_FSTAMP(3);
@@ -213,6 +226,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
     float f[7];
     {
       const float ux = unit_box(a.grid[1].bbox, cx), uy = unit_box(a.grid[1].bbox, cy), uz = unit_box(a.grid[1].bbox, cz);
+#if defined(RC_ABL) && RC_ABL == 11
+      for (int l = 0; l < 7; ++l) f[l] = ux * (float)l + uy - uz;
+#else
       Corners<1> C[7];          // all 56 corner loads in flight before the first combine
 #pragma unroll
       for (int l = 0; l < 7; ++l) { const RcGridLevel& L = a.grid[1].lvl[l]; grid_fetch<1, true, 1, true>(L.dense ? a.cell_table[1][l] : L.table, L.size, L.mask, 0u, L.dense != 0, ux, uy, uz, C[l]); }
@@ -223,9 +239,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
         grid_combine<1, false>(C[l], v, jd);
         f[l] = v[0] * a.grid[1].precondition;
       }
+#endif
     }
     RC_FSTAMP(5);
+#if defined(RC_ABL) && RC_ABL == 13
+    const float raw = f[0] + f[6];
+#else
     const float raw = density_level64<7, F_L1, NF>(ws, act_wave, lane, f);
+#endif
     w = alpha_weight(density_of(raw, cx, cy, cz, a.grid[1].bbox), t0, t1, dnorm, true, lane);
   }
   RC_FSTAMP(6);
@@ -250,6 +271,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
     float f[32];
     const float ux = unit_box(g.bbox, cx), uy = unit_box(g.bbox, cy), uz = unit_box(g.bbox, cz);
     // two rounds of four levels: 32 corner loads of 16 bytes in flight per lane
+#if defined(RC_ABL) && RC_ABL == 11
+    for (int k = 0; k < 32; ++k) f[k] = ux * (float)k + uy - uz;
+    if (false)
+#endif
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       Corners<4> C[4];
@@ -405,8 +430,13 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
 #pragma unroll
   for (int s = 0; s < 16; ++s) act[(32 + s) * 64] = act[(kAppTmp + s) * 64];
   act[48 * 64] = h == 0 ? 1.0f : 0.0f;
+#if defined(RC_ABL) && RC_ABL == 12
+  ShadeOut so;
+  for (int c = 0; c < 3; ++c) { so.rgb[c] = act[c * 64]; so.ad[c] = npx; so.idf[c] = npy; so.is[c] = npz; so.tint[c] = density; }
+#else
   const ShadeOut so = shader_tile<F_SH, NF>(ws, act, lane, h, npx, npy, npz, a.viewdirs[3 * ray], a.viewdirs[3 * ray + 1],
                                             a.viewdirs[3 * ray + 2], reinterpret_cast<const RcIdeTable*>(a.ide_coef), a.sh);
+#endif
 
   RC_FSTAMP(10);
   // ------------------------------------------------------------------ volume compositing (k_composite)

@@ -129,6 +129,18 @@ struct RcDensityMlpArgs {
 };
 void rc_launch_density_mlp(const RcDensityMlpArgs& a, hipStream_t stream);
 
+// One proposal level as one launch (rc_level.hip): grid lookup + density MLP, density only.
+struct RcLevelArgs {
+  const RcGridDev* grid;
+  const float* means;         // SoA [3][n]
+  int64_t n;
+  const float* wstream;       // the level's "dens_<l>" fragment stream
+  float density_bias, contract_radius;
+  float* density;             // [n]
+};
+bool rc_level_supported(const RcGridDev& g);
+void rc_launch_level(const RcLevelArgs& a, hipStream_t stream);
+
 struct RcShaderArgs {
   int64_t n;                  // shaded points
   int64_t n_src;              // points of the last level (stride of the SoA inputs)

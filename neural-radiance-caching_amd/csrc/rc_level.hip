@@ -1,0 +1,173 @@
+// One proposal level of the launch-per-stage plan as ONE launch: contraction + multiresolution grid lookup + density
+// MLP (+ convert_raw_density) per sample, i.e. k_hashgrid_fwd and k_density_mlp fused for the case where only the
+// density of a sample is consumed behind it (proposal levels 0 / 1 always; the last level on the lean resampling pass of
+// secondary rays, whose hidden feature is recomputed for the one picked sample per ray).
+//
+// Replaces, with the arithmetic and the operation order of rc_hashgrid.hip / rc_mlp.hip (bitwise the same densities):
+//   coord.contract, HashEncoding.__call__                           internal/coord.py:37-69, internal/grid_utils.py:808-905
+//   DensityMLP.run_network, convert_raw_density                      internal/geometry.py:155-168, 318-341
+//
+// Why: on the material stage's batched secondary trace (32 768 rays, 2 M + 2 M + 1 M samples) the two kernels per level
+// ran back to back -- with the grid features going through HBM in between, and the MLP at 36-54 % of the MFMA rate
+// because every 128-point workgroup re-streamed the level's weights and paid a start-up.  Here the level's whole weight
+// stream (27-59 KB) is loaded into LDS ONCE per workgroup (one per CU), whose waves then walk independently -- no
+// barrier after the load -- over 32-sample tiles: gather (all corner loads of a lane's levels in flight), features
+// straight into the MFMA B-operand slots, MLP, density.  The two half-waves of a tile split the grid levels by parity,
+// so a lane issues half of a point's loads and, for the F = 1 grids, writes its features into its own B column.
+// Measured on that trace (us per level, before -> after): 462 -> 302, 446 -> 344, 522 -> 389.  The gather half is
+// largely vector-ALU work (contraction, hashing, 64-bit addresses, trilinear weights) and fp32 MFMA shares the vector
+// ALUs, so the two halves mostly ADD inside a SIMD: gather alone 206 / 296 / 372 us, MLP alone 201 / 205 / 135 us.
+// A producer / consumer split of the workgroup (one gather wave per grid level feeding four MLP waves through a
+// double-buffered B-operand ring) was built as well, bitwise equal, and measured slower (343 / 467 / 405 us): it repeats
+// the contraction per level and gains nothing from running the two halves side by side.
+#include "rc_dev_grid.h"
+#include "rc_dev_mlp.h"
+#include "rc_dev_sample.h"
+
+using namespace rcdev;
+
+namespace {
+
+constexpr int kLvActSteps = 33;
+
+template <int F> struct LevelCfg;
+template <> struct LevelCfg<1> { static constexpr int W = 12; };
+template <> struct LevelCfg<4> { static constexpr int W = 8; };
+
+struct RcLevelKArgs {
+  RcGridDev grid;
+  const float* means;          // SoA [3][n]
+  int64_t n;
+  const float* wstream;        // [d0 | d1 | out (+ ...)] fragments of rc_api.hip's "dens_<l>" pack
+  float density_bias, contract_radius;
+  float* density;              // [n]
+};
+
+// NL grid levels of F features: K = NL * F grid features, KS0 = K / 2 (rounded up) + 1 k-steps in layer 0.
+template <int F, int NL>
+__global__ __launch_bounds__(LevelCfg<F>::W * 64) void k_level(RcLevelKArgs a) {
+  constexpr int W = LevelCfg<F>::W;
+  constexpr int K = F * NL, KS0 = (K + 1) / 2 + 1;
+  constexpr int NOB = KS0 == 17 ? 4 : 1;                                   // rows the output layer was packed with
+  constexpr int F_D0 = 0, F_D1 = 2 * KS0, F_DO = 2 * KS0 + 66, NF = F_DO + NOB * 33;
+  constexpr int CH = 288;     // > NF and a multiple of 4 W (ws_issue is instantiated, never run): the whole stream is one resident chunk
+  static_assert(NF <= CH && CH % (4 * W) == 0, "stream must fit the resident chunk");
+  extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  float* wres = lds_dyn;                                                    // [NF padded to 4][64]
+  constexpr int kResFloats = ((NF + 3) / 4) * 4 * 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* act_wave = lds_dyn + kResFloats + wave * (kLvActSteps * 64);
+  float* act = act_wave + lane;
+  // the level's weights: once per workgroup, LDS-DMA in 1-KiB pieces (the packed stream is padded to whole 16-KiB chunks)
+  for (int piece = wave; piece < (NF + 3) / 4; piece += W)
+    __builtin_amdgcn_global_load_lds((const void*)(a.wstream + (size_t)piece * 256 + lane * 4), (lds_void_ptr)(wres + piece * 256), 16, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  WStream ws{a.wstream, wres, lane, wave};
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t tiles = (a.n + 31) / 32;
+  const float bbox = a.grid.bbox;
+  for (int64_t tile = (int64_t)blockIdx.x * W + wave; tile < tiles; tile += (int64_t)gridDim.x * W) {
+    const int64_t p = tile * 32 + j;
+    const bool valid = p < a.n;
+    const int64_t q = valid ? p : a.n - 1;
+    float cx = a.means[q], cy = a.means[a.n + q], cz = a.means[2 * a.n + q];
+    contract3(cx, cy, cz, a.contract_radius);
+    const float ux = unit_box(bbox, cx), uy = unit_box(bbox, cy), uz = unit_box(bbox, cz);
+    // this half-wave's levels: l = 2 i + h (all their corner loads in flight before the first combine)
+    constexpr int NH = (NL + 1) / 2;
+    Corners<F> C[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int l = 2 * i + h;
+      if (l < NL) {
+        const RcGridLevel& L = a.grid.lvl[l];
+        if constexpr (F == 1) {
+          if (L.cell) grid_fetch<1, false, 1, true>(L.cell, L.size, L.mask, L.entries, true, ux, uy, uz, C[i]);
+          else grid_fetch<1>(L.table, L.size, L.mask, L.entries, L.dense != 0, ux, uy, uz, C[i]);
+        } else {
+          grid_fetch<4>(L.table, L.size, L.mask, L.entries, L.dense != 0, ux, uy, uz, C[i]);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (F == 1) {
+      // feature l of point j -> step l / 2, half l & 1 = h: this lane's own column
+#pragma unroll
+      for (int i = 0; i < KS0 - 1; ++i) {
+        const int l = 2 * i + h;
+        float v = 0.0f;
+        if (i < NH && l < NL) {
+          float f[1], jd[1];
+          grid_combine<1, false>(C[i < NH ? i : 0], f, jd);
+          v = f[0] * a.grid.precondition;
+        }
+        act[i * 64] = v;
+      }
+    } else {
+      // F = 4: feature 4 l + c -> step 2 l + c / 2, half c & 1
+#pragma unroll
+      for (int i = 0; i < NH; ++i) {
+        const int l = 2 * i + h;
+        if (l < NL) {
+          float f[4], jd[1];
+          grid_combine<4, false>(C[i], f, jd);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) act_wave[(2 * l + (c >> 1)) * 64 + j + 32 * (c & 1)] = f[c] * a.grid.precondition;
+        }
+      }
+    }
+    act[(KS0 - 1) * 64] = h == 0 ? 1.0f : 0.0f;
+    lds_sync_wave();
+    f32x16 acc[2];
+    acc[0] = zero16(); acc[1] = zero16();
+    mlp_layer<2, KS0, F_D0, NF, 4, W, CH>(ws, act, acc);
+    park<2, true>(acc, act, 0);
+    act[32 * 64] = h == 0 ? 1.0f : 0.0f;
+    acc[0] = zero16(); acc[1] = zero16();
+    mlp_layer<2, 33, F_D1, NF, 4, W, CH>(ws, act, acc);
+    float out[1], nokeep[1];
+    dot_out1<2, 1, F_DO, NF, false, W, NOB, CH>(ws, acc, out, nokeep);     // output_density_layer on relu(acc)
+    if (h == 0 && valid) {
+      // convert_raw_density (geometry.py:318-341)
+      const bool inside = (cx > -bbox) & (cx < bbox) & (cy > -bbox) & (cy < bbox) & (cz > -bbox) & (cz < bbox);
+      const float d = expf(fminf(fmaxf(out[0] + a.density_bias, -RC_FMAX), 70.0f));
+      a.density[p] = inside ? d : 0.0f;
+    }
+    lds_sync_wave();        // the next tile's feature writes must not overtake this tile's activation reads
+  }
+}
+
+template <int F, int NL>
+void launch_level(const RcLevelKArgs& a, hipStream_t stream) {
+  constexpr int W = LevelCfg<F>::W;
+  constexpr int K = F * NL, KS0 = (K + 1) / 2 + 1, NOB = KS0 == 17 ? 4 : 1, NF = 2 * KS0 + 66 + NOB * 33;
+  const int lds = (((NF + 3) / 4) * 4 * 64 + W * kLvActSteps * 64) * (int)sizeof(float);
+  static std::atomic<uint64_t> prepared{0};
+  if (rc_first_use_on_device(prepared))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_level<F, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int64_t tiles = (a.n + 31) / 32;
+  const int64_t want = (tiles + W - 1) / W;
+  dim3 grid((unsigned)(want < cus ? want : cus)), block(W * 64);
+  hipLaunchKernelGGL((k_level<F, NL>), grid, block, lds, stream, a);
+}
+
+}  // namespace
+
+// true when (F, number of levels) is one of the compiled shapes
+bool rc_level_supported(const RcGridDev& g) {
+  return (g.num_features == 1 && (g.num_levels == 6 || g.num_levels == 7)) || (g.num_features == 4 && g.num_levels == 8);
+}
+
+void rc_launch_level(const RcLevelArgs& A, hipStream_t stream) {
+  if (A.n <= 0) return;
+  RcLevelKArgs a{};
+  a.grid = *A.grid; a.means = A.means; a.n = A.n; a.wstream = A.wstream;
+  a.density_bias = A.density_bias; a.contract_radius = A.contract_radius; a.density = A.density;
+  if (a.grid.num_features == 1 && a.grid.num_levels == 6) launch_level<1, 6>(a, stream);
+  else if (a.grid.num_features == 1 && a.grid.num_levels == 7) launch_level<1, 7>(a, stream);
+  else if (a.grid.num_features == 4 && a.grid.num_levels == 8) launch_level<4, 8>(a, stream);
+}

@@ -808,7 +808,7 @@ class RadianceCache:
     def set_fused(self, on: bool):
         """Plain cache pass: True (default) one fused launch per batch with every intermediate on chip,
         False one launch per stage (fills the workspace that `workspace()` shows)."""
-        self._check(self.lib.rc_set_fused(self._h, 1 if on else 0))
+        self._check(self.lib.rc_set_fused(self._h, int(on) if not isinstance(on, bool) else (1 if on else 0)))
 
     def stage_times_ms(self) -> Dict[str, float]:
         n = self.lib.rc_stage_count()

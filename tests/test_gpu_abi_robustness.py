@@ -146,3 +146,32 @@ def test_allgather_outputs_over_rccl_world_of_one():
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("n", [1, 5, 257, 2048])
+def test_level_kernels_equal_the_separate_gather_and_mlp_kernels(n):
+    """rc_set_fused(2): a proposal level that only hands its density on runs as ONE launch (rc_level.hip: grid lookup +
+    density MLP, weights resident in LDS); rc_set_fused(0): k_hashgrid_fwd + k_density_mlp.  Same arithmetic in the same
+    order: primary rays (levels 0 / 1), secondary and resampled rays (all three levels on the lean pass) bitwise equal."""
+    from nrc_amd import rc_ext
+    rc = common.make_rc()
+    rc.set_graph_mode(0)
+    rays = nrc_amd.synthetic_rays(n, seed=31).hot_fields()
+    jit = common.jitters(n, seed=9)
+    srays, srnd = common.secondary_case(n, seed=12)
+    g = np.random.default_rng(4).gumbel(size=(n, 32)).astype(np.float32)
+    cases = [(rays, {"jitter": jit}, rc_ext.RC_PASS_CACHE, None),
+             (rays, {"jitter": jit, "gumbel": g}, rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_RESAMPLE, ["rgb", "acc", "distance_median", "means"]),
+             (srays, srnd, rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_SECONDARY | rc_ext.RC_PASS_NO_ENVMAP, ["rgb", "acc", "distance_mean"])]
+    for fields, rnd, mask, outs in cases:
+        res = {}
+        for mode in (0, 2):
+            rc.set_fused(mode)
+            o = rc.render_rays(fields, rnd, mask, outputs=outs)
+            torch.cuda.synchronize()
+            res[mode] = {k: v.clone() for k, v in o.items()}
+            res[mode]["density0"] = torch.from_numpy(rc.workspace("density0")[: n * 64].copy())
+            res[mode]["density2"] = torch.from_numpy(rc.workspace("density2")[: n * 32].copy())
+        for k in res[0]:
+            assert torch.equal(res[0][k].cpu(), res[2][k].cpu()), (mask, k)
+    rc.set_fused(1)
