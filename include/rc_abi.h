@@ -182,6 +182,10 @@ typedef struct {
    * secondary trace (material.py:2191-2217 -> models.py:193-292).  With both given the noise members may be NULL. */
   const int32_t* resample_inds;     /* [n]          */
   const int32_t* sec_resample_inds; /* [n*(Ks+Kd)]  block [n*Ks | n*Kd] like sec_jitter */
+  /* optional, instead of vmf_lobe (then NULL): standard Gumbel noise [n, 128]; the lobe is drawn on the device as
+   * argmax_j(logit_j + g_j), which is jax.random.categorical(key, logits) of sample_vmf_vars (render_utils.py:1357-1372)
+   * when g = jax.random.gumbel(key, [n, 128]) */
+  const float* vmf_lobe_gumbel;
 } rc_material_randoms;
 
 typedef enum {

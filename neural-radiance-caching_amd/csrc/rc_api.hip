@@ -1470,8 +1470,10 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
   if (K < 2 || Ks < 1 || Kd < 2 || Kc < 1 || Kd - Kc < 1 || Ks + Kd > 64)
     return fail(h, RC_ERR_UNSUPPORTED, "rc_render_material: num_secondary_samples must give 1 <= Ks, 2 <= Kd, Ks + Kd <= 64");
   if (c.num_vmf != 128) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_material: num_vmf must be 128");
-  if (!mr->vmf_noise || !mr->spec_u1 || !mr->spec_u2 || !mr->cos_u1 || !mr->cos_u2 || !mr->vmf_lobe || !mr->vmf_v || !mr->vmf_tmp)
-    return fail(h, RC_ERR_INVALID_ARG, "rc_render_material: every sampler member of rc_material_randoms is required");
+  if (!mr->vmf_noise || !mr->spec_u1 || !mr->spec_u2 || !mr->cos_u1 || !mr->cos_u2 || !mr->vmf_v || !mr->vmf_tmp ||
+      !(mr->vmf_lobe || mr->vmf_lobe_gumbel))
+    return fail(h, RC_ERR_INVALID_ARG, "rc_render_material: every sampler member of rc_material_randoms is required "
+                                       "(vmf_lobe or vmf_lobe_gumbel)");
   if (!(mr->gumbel || mr->resample_inds) || !(mr->sec_gumbel || mr->sec_resample_inds))
     return fail(h, RC_ERR_INVALID_ARG, "rc_render_material: the categorical picks need gumbel or resample_inds (primary) and "
                                        "sec_gumbel or sec_resample_inds (secondary trace)");
@@ -1565,7 +1567,7 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     sa.pts = W(h, "m_pts"); sa.nrm = W(h, "m_nrm"); sa.viewdirs = rays->viewdirs; sa.lights = rays->lights;
     sa.mat = W(h, "m_mat"); sa.vmf = W(h, "l_vmf");
     sa.spec_u1 = mr->spec_u1; sa.spec_u2 = mr->spec_u2; sa.cos_u1 = mr->cos_u1; sa.cos_u2 = mr->cos_u2;
-    sa.vmf_lobe = mr->vmf_lobe; sa.vmf_v = mr->vmf_v; sa.vmf_tmp = mr->vmf_tmp;
+    sa.vmf_lobe = mr->vmf_lobe; sa.vmf_v = mr->vmf_v; sa.vmf_tmp = mr->vmf_tmp; sa.vmf_lobe_gumbel = mr->vmf_lobe_gumbel;
     sa.normal_eps = c.secondary_normal_eps; sa.near = c.secondary_near; sa.far = c.secondary_far;
     sa.sec_origins = W(h, "sec_origins"); sa.sec_dirs = W(h, "sec_dirs"); sa.sec_near = W(h, "sec_near");
     sa.sec_far = W(h, "sec_far"); sa.sec_lights = W(h, "sec_lights"); sa.samples = W(h, "sec_samples");

@@ -212,6 +212,7 @@ struct RcBrdfSampleArgs {
   const float* pts; const float* nrm; const float* viewdirs; const float* lights; const float* mat; const float* vmf;
   const float* spec_u1; const float* spec_u2; const float* cos_u1; const float* cos_u2;
   const int32_t* vmf_lobe; const float* vmf_v; const float* vmf_tmp;
+  const float* vmf_lobe_gumbel;   // [n,128] or nullptr: lobe = argmax(log weight + gumbel) when vmf_lobe is nullptr
   float normal_eps, near, far;
   float* sec_origins; float* sec_dirs; float* sec_near; float* sec_far; float* sec_lights;   // [n*(Ks+Kd), .]
   float* samples;       // [n, Ks+Kd, RC_SMP_CH]

@@ -220,6 +220,29 @@ __global__ __launch_bounds__(256) void k_brdf_sample(RcBrdfSampleArgs a) {
   __syncthreads();
   const float* vm = s_vmf[wave];
   const float* den = s_den[wave];
+  // sample_vmf_vars (render_utils.py:1357-1372): ONE lobe per point, given or drawn here as argmax_j(logit_j + g_j)
+  // (= jax.random.categorical; log of the softmax weight differs from the logit by a constant of the point)
+  int lobe;
+  if (a.vmf_lobe) {
+    lobe = a.vmf_lobe[r];
+  } else {
+    float key = -INFINITY;
+    int best = lane;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int jj = lane + 64 * q;
+      const float kq = logf(fmaxf(vm[jj * RC_VMF_CH + 4], RC_TINY)) + a.vmf_lobe_gumbel[r * 128 + jj];
+      if (kq > key) { key = kq; best = jj; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const float ok = __shfl_xor(key, d, 64);
+      const int ob = __shfl_xor(best, d, 64);
+      if (ok > key || (ok == key && ob < best)) { key = ok; best = ob; }
+    }
+    lobe = best;
+  }
+  lobe = min(max(lobe, 0), 127);
   const int Ks = a.Ks, Kd = a.Kd, Kc = a.Kc, K = Ks + Kd;
   const V3 nrm = {a.nrm[3 * r], a.nrm[3 * r + 1], a.nrm[3 * r + 2]};
   const V3 pt = {a.pts[3 * r], a.pts[3 * r + 1], a.pts[3 * r + 2]};
@@ -272,7 +295,7 @@ __global__ __launch_bounds__(256) void k_brdf_sample(RcBrdfSampleArgs a) {
       } else {
         // LightSampler -> sample_vmf (render_utils.py:1390-1428): all directions from ONE lobe per point
         const int kl = kd - Kc, Kl = Kd - Kc;
-        const float* q = vm + a.vmf_lobe[r] * RC_VMF_CH;
+        const float* q = vm + lobe * RC_VMF_CH;
         const V3 mean = {q[0], q[1], q[2]};
         const float kappa = q[3];
         const V3 tv = l2_normalize(V3{-mean.y, mean.x, 0.0f});

@@ -221,3 +221,92 @@ def light_vmf_noise(shape, seed: int = 1) -> np.ndarray:
     vmf_params.shape[:-1] + (3,)); the caller scales it by vmf_scale / 2."""
     key, _ = random_split(PRNGKey(seed))
     return normal(key, tuple(shape))
+
+
+def material_pass_randoms(model_rng, n_rays: int, cfg) -> Dict[str, object]:
+    """Explicit random tensors of ONE material-stage forward (the dict rc_material_randoms / Model.apply(passes=
+    ("cache", "light", "material")) take) derived from the model's rng at the reference's split sites:
+
+      BaseMaterialModel.__call__            models.py:1156 (bypass), 1177 (cache pass), 1195 (_get_material_samples),
+                                            1208 (light sampler), 1220 (_handle_material_pass)
+      _get_material_samples                 models.py:1417 (first maybe_resample, no draw), 1431 (MaterialModel's resample)
+        maybe_resample                      models.py:241 -> jax.random.categorical == argmax(logits + gumbel[R, S, 1])
+      _handle_material_pass -> shader       models.py:1548; shading.py:289; material.py:1971, 1988, 2030, 2535
+      get_outgoing_radiance                 material.py:1383 (indirect specular), 1416 (indirect diffuse); 1642, 1721, 1780
+      get_secondary_rays / importance_...   render_utils.py:962, 767 + 324 (uh, uw = uniform(key, [N K, 2])), 784
+      LightSampler.sample_directions        render_utils.py:1450, 1407, 1358 (lobe: categorical over 128 logits),
+                                            1409 (normal [N, K, 2]), 1413 (uniform [N, K])
+      secondary cache calls                 material.py:2190; models.py:712 / 727 (resample gumbel [R, K, S, 1]);
+                                            their sampler runs on the constant PRNGKey(0) at render time
+                                            (sampling.py:170-179) -- the specular and the diffuse trace therefore draw the
+                                            SAME per-level jitter
+    The call order is restated from the source and cannot be checked against a jax run here (no jax in the image)."""
+    K = int(cfg.num_secondary_samples)
+    Kd = int(round(K * cfg.diffuse_sample_fraction))
+    Ks = int(round(K * (1.0 - cfg.diffuse_sample_fraction)))
+    Kc = int(round(0.5 * Kd))
+    Kl = Kd - Kc
+    levels = [lvl[2] for lvl in cfg.sampling_strategy]
+    S = int(levels[-1])
+    rng = as_key(model_rng)
+    out = dict(cache_pass_randoms(rng, n_rays, levels, resample=False))           # primary rays' jitter
+    _, rng = random_split(rng)                # :1156
+    _, rng = random_split(rng)                # :1177
+    k_samples, rng = random_split(rng)        # :1195
+    _, rng = random_split(rng)                # :1208 (LightMLP draws nothing from it: its noise is the PRNGKey(1) constant)
+    k_mat, rng = random_split(rng)            # :1220
+    # -- categorical pick of the shading sample
+    _, r = random_split(k_samples)            # :1417
+    k2, r = random_split(r)                   # :1431
+    kg, _ = random_split(k2)                  # :241
+    out["gumbel"] = gumbel(kg, (n_rays, S, 1))[..., 0]
+    out["vmf_noise"] = light_vmf_noise((n_rays, 1, int(cfg.num_vmf), 3))[:, 0]
+    # -- material shader
+    k_sh, _ = random_split(k_mat)             # models.py:1548
+    k_pa, _ = random_split(k_sh)              # shading.py:289
+    _, r = random_split(k_pa)                 # material.py:1971
+    _, r = random_split(r)                    # :1988
+    k_int, _ = random_split(r)                # :2030
+    k_out, _ = random_split(k_int)            # :2535
+    k_spec, r = random_split(k_out)           # :1383 indirect specular
+    k_diff, r = random_split(r)               # :1416 indirect diffuse (the env-map passes reuse these rays)
+
+    def one_pass(k_pass, counts):
+        """counts: samples per sampler, in sampler order.  Returns ([(uh, uw, sampler_rng)], key of the cache call)."""
+        kh, _ = random_split(k_pass)          # :1642
+        kh1, r2 = random_split(kh)            # :1721 get_secondary_rays
+        kh2, _ = random_split(r2)             # :1780 radiance_cache_fn
+        ki, _ = random_split(kh1)             # render_utils.py:962
+        draws, r3 = [], ki
+        for cnt in counts:
+            ka, r3 = random_split(r3)         # :767
+            ku, _ = random_split(ka)          # :324
+            u = uniform(ku, (n_rays * cnt, 2))
+            kb, r3 = random_split(r3)         # :784
+            draws.append((u[:, 0].reshape(n_rays, cnt), u[:, 1].reshape(n_rays, cnt), kb))
+        kc, _ = random_split(kh2)             # material.py:2190
+        return draws, kc
+
+    def trace_randoms(kc, Kp):
+        ck = cache_keys(kc)                   # models.py:712 (sampler: replaced by PRNGKey(0)), 727, 748
+        kg2, _ = random_split(ck["resample"])  # :241
+        jit = sampler_randoms(PRNGKey(0), n_rays * Kp, levels)
+        return jit, gumbel(kg2, (n_rays, Kp, S, 1))[..., 0].reshape(n_rays * Kp, S)
+
+    (su1, su2, _), = one_pass(k_spec, [Ks])[0]
+    _, kc_spec = one_pass(k_spec, [Ks])
+    out["spec_u1"], out["spec_u2"] = su1, su2
+    out["spec_jitter"], out["spec_gumbel"] = trace_randoms(kc_spec, Ks)
+    draws, kc_diff = one_pass(k_diff, [Kc, Kl])
+    out["cos_u1"], out["cos_u2"] = draws[0][0], draws[0][1]
+    k_light = draws[1][2]
+    ks, _ = random_split(k_light)             # LightSampler.sample_directions (render_utils.py:1450)
+    kv1, r5 = random_split(ks)                # sample_vmf :1407
+    kl, _ = random_split(kv1)                 # sample_vmf_vars :1358
+    out["vmf_lobe_gumbel"] = gumbel(kl, (n_rays, int(cfg.num_vmf)))
+    kn, r5 = random_split(r5)                 # :1409
+    out["vmf_v"] = normal(kn, (n_rays, Kl, 2))
+    kt, _ = random_split(r5)                  # :1413
+    out["vmf_tmp"] = uniform(kt, (n_rays, Kl))
+    out["diff_jitter"], out["diff_gumbel"] = trace_randoms(kc_diff, Kd)
+    return out

@@ -94,7 +94,7 @@ class rc_material_randoms(C.Structure):
     _fields_ = [("gumbel", C.c_void_p), ("vmf_noise", C.c_void_p), ("spec_u1", C.c_void_p), ("spec_u2", C.c_void_p),
                 ("cos_u1", C.c_void_p), ("cos_u2", C.c_void_p), ("vmf_lobe", C.c_void_p), ("vmf_v", C.c_void_p),
                 ("vmf_tmp", C.c_void_p), ("sec_jitter", C.c_void_p * RC_MAX_LEVELS), ("sec_gumbel", C.c_void_p),
-                ("resample_inds", C.c_void_p), ("sec_resample_inds", C.c_void_p)]
+                ("resample_inds", C.c_void_p), ("sec_resample_inds", C.c_void_p), ("vmf_lobe_gumbel", C.c_void_p)]
 
 
 class rc_mat_outputs(C.Structure):
@@ -705,8 +705,12 @@ class RadianceCache:
                 continue                      # the primary pick is handed over as resample_inds
             held["m_" + k] = self._dev(randoms[k])
             setattr(mr, k, held["m_" + k].data_ptr())
-        held["m_lobe"] = self._dev(randoms["vmf_lobe"], torch.int32).reshape(-1)
-        mr.vmf_lobe = held["m_lobe"].data_ptr()
+        if randoms.get("vmf_lobe") is not None:
+            held["m_lobe"] = self._dev(randoms["vmf_lobe"], torch.int32).reshape(-1)
+            mr.vmf_lobe = held["m_lobe"].data_ptr()
+        else:                                 # the lobe is drawn on the device: argmax(logits + Gumbel noise)
+            held["m_lobe_g"] = self._dev(randoms["vmf_lobe_gumbel"]).reshape(n, -1)
+            mr.vmf_lobe_gumbel = held["m_lobe_g"].data_ptr()
         # secondary trace randoms: [specular block | diffuse block]
         for l in range(RC_MAX_LEVELS):
             held[f"sj{l}"] = torch.cat([self._dev(randoms["spec_jitter"][l]).reshape(-1),

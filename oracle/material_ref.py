@@ -282,7 +282,7 @@ def _secondary_trace(weights, cfg, origins, dirs, lights, jitter, gumbel, inds=N
     rays = dict(origins=origins, directions=dirs, viewdirs=dirs, lights=lights,
                 near=torch.full((n, 1), cfg.secondary_near, dtype=dt), far=torch.full((n, 1), cfg.secondary_far, dtype=dt),
                 lossmult=torch.ones((n, 1), dtype=dt))
-    out = cache_ref.cache_forward(weights, cfg, rays, [torch.as_tensor(j)[:, None] for j in jitter], is_secondary=True,
+    out = cache_ref.cache_forward(weights, cfg, rays, [torch.as_tensor(j).reshape(-1, 1) for j in jitter], is_secondary=True,
                                   gumbel=None if gumbel is None else torch.as_tensor(gumbel),
                                   inds=None if inds is None else torch.as_tensor(inds).long().reshape(-1, 1),
                                   use_env_map=False, want_grad_normals=False)
@@ -297,7 +297,7 @@ def material_forward(weights, cfg, rays, rnd, want_grad_normals=False):
     dt = rays["origins"].dtype
     T = lambda a: torch.as_tensor(a).to(dt) if not torch.is_tensor(a) or a.is_floating_point() else torch.as_tensor(a)
     # --- cache pass on the primary rays (all 32 samples shaded)
-    cache = cache_ref.cache_forward(weights, cfg, rays, [T(j)[:, None] for j in rnd["jitter"]],
+    cache = cache_ref.cache_forward(weights, cfg, rays, [T(j).reshape(-1, 1) for j in rnd["jitter"]],
                                     want_grad_normals=want_grad_normals)
     geo = cache["sampler"][-1]
     # --- _get_material_samples: categorical resample to one sample per ray
@@ -317,8 +317,11 @@ def material_forward(weights, cfg, rays, rnd, want_grad_normals=False):
     gview = -view
     origins = pts + nrm * cfg.secondary_normal_eps
     spec = sample_specular(gview, nrm, mat, T(rnd["spec_u1"]), T(rnd["spec_u2"]))
-    diff = sample_diffuse(gview, nrm, mat, T(rnd["cos_u1"]), T(rnd["cos_u2"]), vmfs, torch.as_tensor(rnd["vmf_lobe"]).long(),
-                          T(rnd["vmf_v"]), T(rnd["vmf_tmp"]))
+    if rnd.get("vmf_lobe") is not None:
+        lobe = torch.as_tensor(rnd["vmf_lobe"]).long()
+    else:       # sample_vmf_vars (render_utils.py:1357-1372): categorical over the lobe logits = argmax(logits + Gumbel noise)
+        lobe = torch.argmax(vmfs["vmf_logits"][..., 0] + T(rnd["vmf_lobe_gumbel"]), dim=-1)
+    diff = sample_diffuse(gview, nrm, mat, T(rnd["cos_u1"]), T(rnd["cos_u2"]), vmfs, lobe, T(rnd["vmf_v"]), T(rnd["vmf_tmp"]))
     integ = {}
     dbg = {}
     for name, s, kind, jit, gum, sinds in (
@@ -391,4 +394,4 @@ def material_forward(weights, cfg, rays, rnd, want_grad_normals=False):
     render["vignette"] = torch.ones_like(render["rgb"][..., :1])
     render["lossmult"] = torch.ones_like(render["rgb"][..., :1])     # models.py:2046-2053 (all-true mask)
     return {"render": render, "cache": cache, "inds": inds, "debug": dbg, "material": mat, "vmfs": vmfs,
-            "shader": sh, "filtered": filt}
+            "shader": sh, "filtered": filt, "lobe": lobe}

@@ -187,3 +187,65 @@ def test_render_camera_with_key_draws_the_chunk_keys_of_render_image():
         assert np.array_equal(a[k].reshape(-1), b[k].reshape(-1)), k
     d = render_camera(model, cam, H, W, rows_per_chunk=16, rng=None)
     assert not np.array_equal(a["rgb"], d["rgb"])
+
+
+def test_material_pass_randoms_from_a_key():
+    """prng.material_pass_randoms: every random tensor of the material stage derived from ONE model key at the
+    reference's split sites (shapes of rc_material_randoms; deterministic; the two secondary traces share the
+    PRNGKey(0) jitter of sampling.py:170-179; different keys give different draws; the primary jitter is the cache pass's)."""
+    import nrc_amd
+    cfg = nrc_amd.hotdog_config()
+    n = 6
+    a = prng.material_pass_randoms(prng.PRNGKey(11), n, cfg)
+    b = prng.material_pass_randoms(prng.PRNGKey(11), n, cfg)
+    c = prng.material_pass_randoms(prng.PRNGKey(12), n, cfg)
+    want = {"gumbel": (n, 32), "vmf_noise": (n, 128, 3), "spec_u1": (n, 16), "spec_u2": (n, 16), "cos_u1": (n, 8),
+            "cos_u2": (n, 8), "vmf_lobe_gumbel": (n, 128), "vmf_v": (n, 8, 2), "vmf_tmp": (n, 8),
+            "spec_gumbel": (n * 16, 32), "diff_gumbel": (n * 16, 32)}
+    for k, shp in want.items():
+        assert a[k].shape == shp and a[k].dtype == np.float32, k
+        assert np.array_equal(a[k], b[k]), k
+    for k in ("gumbel", "spec_u1", "cos_u2", "vmf_lobe_gumbel", "vmf_v", "vmf_tmp", "spec_gumbel", "diff_gumbel"):
+        assert not np.array_equal(a[k], c[k]), k
+    assert np.array_equal(a["vmf_noise"], c["vmf_noise"])              # the PRNGKey(1) constant of LightMLP.get_vmfs
+    for l in range(3):
+        assert a["spec_jitter"][l].shape == (n * 16, 1)
+        assert np.array_equal(a["spec_jitter"][l], a["diff_jitter"][l])         # both traces sample with PRNGKey(0)
+        assert np.array_equal(a["spec_jitter"][l], c["spec_jitter"][l])         # ... whatever the model key
+        assert np.array_equal(a["jitter"][l], prng.cache_pass_randoms(prng.PRNGKey(11), n, [64, 64, 32])["jitter"][l])
+    assert not np.array_equal(a["spec_gumbel"], a["diff_gumbel"])
+    for k in ("spec_u1", "spec_u2", "cos_u1", "cos_u2", "vmf_tmp"):
+        assert 0.0 <= a[k].min() and a[k].max() < 1.0
+
+
+@pytest.mark.gpu
+def test_material_stage_from_a_key_matches_the_oracle_on_the_same_tensors():
+    """Model.apply(passes=("cache", "light", "material"), rng=key): the tensors are derived from the key
+    (prng.material_pass_randoms), the vMF lobe is drawn on the device from its Gumbel noise; against the oracle fed with
+    the same tensors: equal picks / lobes on (nearly) all rays and, on those, tight values (smooth field)."""
+    import torch
+    import common
+    import nrc_amd
+    from nrc_amd.model import Model
+    from oracle import material_ref
+    cfg = nrc_amd.hotdog_config()
+    wn = common.weights_material_np(True)
+    m = Model(cfg, 0)
+    m.load_variables(wn)
+    n = 96
+    rays = nrc_amd.synthetic_rays(n, seed=41)
+    key = prng.PRNGKey(2024)
+    out = m.apply(None, key, rays, passes=("cache", "light", "material"))["render"]
+    torch.cuda.synchronize()
+    rnd = prng.material_pass_randoms(key, n, cfg)
+    ref = material_ref.material_forward(common.to_torch(wn), cfg, common.rays_torch(rays), rnd)
+    same = m.rc.workspace("inds", np.int32)[:n] == ref["inds"][:, 0].numpy()
+    assert same.mean() >= 0.97
+    sec_same = (m.rc.workspace("s:inds", np.int32)[: n * 32].reshape(2, n, 16) ==
+                np.stack([ref["debug"]["specular"]["inds"].numpy().reshape(n, 16), ref["debug"]["diffuse"]["inds"].numpy().reshape(n, 16)])).all(axis=(0, 2))
+    ok = same & sec_same
+    assert ok.mean() >= 0.9
+    r = ref["render"]
+    for k in ("rgb", "diffuse_rgb", "specular_rgb", "lighting_irradiance", "material_albedo"):
+        d = np.abs(out[k].cpu().numpy() - r[k].numpy().reshape(out[k].shape))[ok]
+        assert d.max() <= 1e-4, (k, d.max())
