@@ -116,6 +116,7 @@ struct rc_handle {
   int n_taps = 0;
   // fused per-ray kernel for the plain cache pass (fused_mode: 0 never, 1 whenever eligible)
   int fused_mode = 1;
+  int fused_direct = getenv("RC_FUSED_DIRECT") ? atoi(getenv("RC_FUSED_DIRECT")) : 0;   // experiment switch (see rc_fused.hip, DIRECT)
   bool fused_ok = false;
   bool fused_front_ok = false;               // transient handles: the FRONT variant of the fused kernel is usable
   // hipGraph replay of the launch sequence (graph_mode: 0 off, 1 capture when a call repeats, 2 always)
@@ -1098,6 +1099,7 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     F.roughness_bias = c.roughness_bias; F.irradiance_bias = c.irradiance_bias; F.ambient_bias = c.ambient_irradiance_bias;
     F.rgb_max = c.rgb_max; F.slf_ambient_bias = c.slf_ambient_bias;
     F.out = A.out;
+    F.direct = h->fused_direct;
     // profiling: the single launch is reported as the "shader" stage, every other stage as 0
     for (int i = 0; i <= ST_SHADER; ++i) stage_mark(h, slot, i, st);
     rc_launch_fused(F, st);

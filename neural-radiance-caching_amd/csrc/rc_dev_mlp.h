@@ -76,13 +76,24 @@ __device__ __forceinline__ float ws_read(const WStream& w, int f) {
   return w.ring[(f % (2 * CH)) * 64 + w.lane];
 }
 
+// The same fragment stream read straight from global memory (L2-resident: one kernel's stream is <= 0.7 MB), one
+// coalesced 256-byte load per fragment and wave, no LDS ring and therefore NO workgroup barriers: the waves of a
+// workgroup are free to drift apart.  Which stream type a kernel uses is a property of the kernel; the arithmetic
+// (fragment order, MFMA order) is identical.
+struct WDirect {
+  const float* g;
+  int lane;
+};
+template <int NF, int W = kWaves, int CH = kChunk>
+__device__ __forceinline__ float ws_read(const WDirect& w, int f) { return w.g[(size_t)f * 64 + w.lane]; }
+
 // One pass over KS k-steps for NT output tiles; the layer's fragments are [FBASE, FBASE + KS*NT)
 // of the stream.  act: this lane's activation column (act[s * 64] is step s).
 // Software pipelined in groups of SG k-steps: the LDS reads (A fragments + B activations) of group
 // g+1 are issued before the MFMAs of group g, with scheduling fences so they stay there; the MFMA
 // pipe then runs back to back while the next operands are in flight.
-template <int NT, int KS, int FBASE, int NF, int SG = (NT >= 8 ? 1 : (NT >= 4 ? 2 : (NT >= 2 ? 4 : 8))), int W = kWaves, int CH = kChunk>
-__device__ __forceinline__ void mlp_layer(const WStream& w, const float* act, f32x16 (&acc)[NT]) {
+template <int NT, int KS, int FBASE, int NF, int SG = (NT >= 8 ? 1 : (NT >= 4 ? 2 : (NT >= 2 ? 4 : 8))), int W = kWaves, int CH = kChunk, class WS = WStream>
+__device__ __forceinline__ void mlp_layer(const WS& w, const float* act, f32x16 (&acc)[NT]) {
   constexpr int NG = (KS + SG - 1) / SG;
   float a[3][SG][NT], b[3][SG];
   auto load = [&](int g, int buf) {
@@ -94,8 +105,7 @@ __device__ __forceinline__ void mlp_layer(const WStream& w, const float* act, f3
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int f = FBASE + s * NT + t;            // compile-time after unrolling
-          if (f > 0 && f % CH == 0) ws_advance<NF, W, CH>(w, f / CH);
-          a[buf][d][t] = w.ring[(f % (2 * CH)) * 64 + w.lane];
+          a[buf][d][t] = ws_read<NF, W, CH>(w, f);
         }
       }
     }
@@ -127,8 +137,8 @@ __device__ __forceinline__ void mlp_layer(const WStream& w, const float* act, f3
 
 // Same as mlp_layer for PT point-tiles per wave (64 points): every A fragment read from the ring feeds
 // PT MFMAs.  Tile p's activation column starts at act + p * tile_stride.
-template <int PT, int NT, int KS, int FBASE, int NF, int SG = (NT * PT >= 8 ? 1 : (NT * PT >= 4 ? 2 : 4)), int W = kWaves>
-__device__ __forceinline__ void mlp_layer_pt(const WStream& w, const float* act, int tile_stride, f32x16 (&acc)[PT][NT]) {
+template <int PT, int NT, int KS, int FBASE, int NF, int SG = (NT * PT >= 8 ? 1 : (NT * PT >= 4 ? 2 : 4)), int W = kWaves, class WS = WStream>
+__device__ __forceinline__ void mlp_layer_pt(const WS& w, const float* act, int tile_stride, f32x16 (&acc)[PT][NT]) {
   constexpr int NG = (KS + SG - 1) / SG;
   float a[3][SG][NT], b[3][SG][PT];
   auto load = [&](int g, int buf) {
@@ -141,8 +151,7 @@ __device__ __forceinline__ void mlp_layer_pt(const WStream& w, const float* act,
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int f = FBASE + s * NT + t;
-          if (f > 0 && f % kChunk == 0) ws_advance<NF, W>(w, f / kChunk);
-          a[buf][d][t] = w.ring[(f % (2 * kChunk)) * 64 + w.lane];
+          a[buf][d][t] = ws_read<NF, W, kChunk>(w, f);
         }
       }
     }
@@ -190,8 +199,8 @@ __device__ __forceinline__ void park(const f32x16 (&acc)[NT], float* act, int ba
 // normals starts from them).  Two partial sums per output (even / odd registers), the two half-waves added last.
 // NOB: outputs the layer was packed with (the bias fragments sit behind NOB * NT * 16 weight fragments); a caller
 // that needs only the first NO < NOB outputs skips the rest.  CH: fragments per ring chunk (see ws_issue).
-template <int PT, int NT, int NO, int FBASE, int NF, bool KEEP = false, int W = kWaves, int NOB = NO, int CH = kChunk>
-__device__ __forceinline__ void dot_out(const WStream& w, const f32x16 (&hid)[PT][NT], float (&out)[PT][NO],
+template <int PT, int NT, int NO, int FBASE, int NF, bool KEEP = false, int W = kWaves, int NOB = NO, int CH = kChunk, class WS = WStream>
+__device__ __forceinline__ void dot_out(const WS& w, const f32x16 (&hid)[PT][NT], float (&out)[PT][NO],
                                         float (&keep)[KEEP ? NT * 16 : 1]) {
   float part[PT][NO][2];
 #pragma unroll
@@ -220,12 +229,12 @@ __device__ __forceinline__ void dot_out(const WStream& w, const f32x16 (&hid)[PT
     }
   }
 }
-template <int NT, int NO, int FBASE, int NF, bool KEEP = false, int W = kWaves, int NOB = NO, int CH = kChunk>
-__device__ __forceinline__ void dot_out1(const WStream& w, const f32x16 (&hid)[NT], float (&out)[NO],
+template <int NT, int NO, int FBASE, int NF, bool KEEP = false, int W = kWaves, int NOB = NO, int CH = kChunk, class WS = WStream>
+__device__ __forceinline__ void dot_out1(const WS& w, const f32x16 (&hid)[NT], float (&out)[NO],
                                          float (&keep)[KEEP ? NT * 16 : 1]) {
   const f32x16 (&h1)[1][NT] = reinterpret_cast<const f32x16 (&)[1][NT]>(hid);
   float (&o1)[1][NO] = reinterpret_cast<float (&)[1][NO]>(out);
-  dot_out<1, NT, NO, FBASE, NF, KEEP, W, NOB, CH>(w, h1, o1, keep);
+  dot_out<1, NT, NO, FBASE, NF, KEEP, W, NOB, CH, WS>(w, h1, o1, keep);
 }
 
 __device__ __forceinline__ float softplus(float x) {
@@ -293,8 +302,8 @@ struct ShadeOut { float rgb[3], ad[3], idf[3], is[3], tint[3]; };
 #else
 #define RC_TSTAMP(i) do { } while (0)
 #endif
-template <int F0, int NF>
-__device__ __forceinline__ ShadeOut shader_tile(const WStream& ws, float* act, int lane, int h, float nx, float ny, float nz,
+template <int F0, int NF, class WS = WStream>
+__device__ __forceinline__ ShadeOut shader_tile(const WS& ws, float* act, int lane, int h, float nx, float ny, float nz,
                                                 float vx, float vy, float vz, const RcIdeTable* tb, const ShaderConsts& k,
                                                 unsigned long long* st = nullptr) {
   RC_TSTAMP(0);

@@ -19,6 +19,7 @@
 #include "rc_dev_grid.h"
 #include "rc_dev_mlp.h"
 #include "rc_dev_sample.h"
+#include <type_traits>
 
 using namespace rcdev;
 
@@ -42,8 +43,8 @@ constexpr int NF_FUSED = F_SH + ShaderFrags::COUNT;
 
 // Density MLP of a proposal level on 64 samples (two point-tiles); returns the raw density of
 // sample `lane`.  K grid features of this lane's sample are in f[].
-template <int K, int FB, int NF>
-__device__ __forceinline__ float density_level64(const WStream& ws, float* act_wave, int lane, const float (&f)[K]) {
+template <int K, int FB, int NF, class WS>
+__device__ __forceinline__ float density_level64(const WS& ws, float* act_wave, int lane, const float (&f)[K]) {
   constexpr int KS0 = (K + 1) / 2 + 1;
   using FR = DensFrags<KS0>;
   const int tile = lane >> 5, j = lane & 31, h = lane >> 5;
@@ -110,7 +111,13 @@ struct RcFusedArgs {
 
 // FRONT: stop behind the last proposal level (density MLP + appearance lookup) and hand the per-sample results to the
 // stages of the time-resolved cache; the stream then ends at F_SH.
-template <bool GRAD, bool FRONT = false>
+// DIRECT (experiment, -DRC_FUSED_DIRECT_EXPERIMENT + RC_FUSED_DIRECT=1): the weight fragments come straight from global
+// memory (WDirect: L2-resident, one coalesced 256-byte load per fragment) instead of through the workgroup's LDS ring:
+// no ring, no workgroup barrier anywhere in the kernel, so the four rays of a workgroup drift apart and their gather
+// phases stop queueing behind each other in the CU's memory pipe.  Bitwise equal results; measured 145 us per 1024 rays
+// against 132 us through the ring: 2165 extra vector loads per ray and their L2 latency cost more than the 40 barriers
+// and the lockstep.  Kept as a template parameter, not instantiated in the product build.
+template <bool GRAD, bool FRONT = false, bool DIRECT = false>
 __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
   constexpr int NF = FRONT ? F_SH : NF_FUSED;
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
@@ -124,13 +131,15 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
   float* s_sd[2] = {scr, scr + 68};
   float* s_td = scr + 2 * 68; float* s_cw = scr + 3 * 68; float* s_c = scr + 4 * 68; float* s_v = scr + 5 * 68;
   float* s_out = scr + 6 * 68;
-  WStream ws{a.wstream, ring, lane, wave};
+  typename std::conditional<DIRECT, WDirect, WStream>::type ws;
+  if constexpr (DIRECT) { ws.g = a.wstream; ws.lane = lane; }
+  else { ws.g = a.wstream; ws.ring = ring; ws.lane = lane; ws.wave = wave; }
 #ifdef RC_STAMPS
   unsigned long long stamps[16];
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
   RC_FSTAMP(0);
-  ws_begin<NF>(ws);
+  if constexpr (!DIRECT) ws_begin<NF>(ws);
 
   const float ox = a.origins[3 * ray], oy = a.origins[3 * ray + 1], oz = a.origins[3 * ray + 2];
   const float dx = a.directions[3 * ray], dy = a.directions[3 * ray + 1], dz = a.directions[3 * ray + 2];
@@ -397,7 +406,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
       }
       ngx = gzx / a.contract_radius; ngy = gzy / a.contract_radius; ngz = gzz / a.contract_radius;
       neg_normalize(ngx, ngy, ngz);
-    } else if constexpr (!FRONT) {
+    } else if constexpr (!FRONT && !DIRECT) {
       // the stream is consumed strictly in order: step the ring over the unused backward fragments
 #pragma unroll
       for (int f = F_L2 + FR::B1; f < F_SH; ++f)
@@ -566,6 +575,10 @@ void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+#ifdef RC_FUSED_DIRECT_EXPERIMENT
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+#endif
   }
   RcFusedArgs a{};
   a.origins = L.rays.origins; a.directions = L.rays.directions; a.viewdirs = L.rays.viewdirs; a.near = L.rays.near;
@@ -598,6 +611,13 @@ void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream) {
     else hipLaunchKernelGGL((k_cache_fused<false, true>), grid, block, lds, stream, a);
     return;
   }
+#ifdef RC_FUSED_DIRECT_EXPERIMENT      // measured 145.3 us against 132.2 us through the ring (same box, bitwise equal results): not built by default
+  if (L.direct) {
+    if (L.out.ptr[RC_OUT_NORMALS]) hipLaunchKernelGGL((k_cache_fused<true, false, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((k_cache_fused<false, false, true>), grid, block, lds, stream, a);
+    return;
+  }
+#endif
   if (L.out.ptr[RC_OUT_NORMALS]) hipLaunchKernelGGL(k_cache_fused<true>, grid, block, lds, stream, a);
   else hipLaunchKernelGGL(k_cache_fused<false>, grid, block, lds, stream, a);
 }

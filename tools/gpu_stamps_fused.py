@@ -9,7 +9,7 @@ cfg = nrc_amd.hotdog_config()
 rc = rc_ext.RadianceCache(cfg, 0); rc.load_weights(nrc_amd.synthetic_weights(cfg))
 rc.set_graph_mode(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-outs = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+outs = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] else None
 rays = nrc_amd.synthetic_rays(n)
 f = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in rays.hot_fields().items()}
 for _ in range(5): rc.render_rays(f, None, outputs=outs) if outs else rc.render_rays(f, None)
