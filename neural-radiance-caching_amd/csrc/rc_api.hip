@@ -116,7 +116,11 @@ struct rc_handle {
   int n_taps = 0;
   // fused per-ray kernel for the plain cache pass (fused_mode: 0 never, 1 whenever eligible)
   int fused_mode = 1;
+#ifdef RC_FUSED_DIRECT_EXPERIMENT
   int fused_direct = getenv("RC_FUSED_DIRECT") ? atoi(getenv("RC_FUSED_DIRECT")) : 0;   // experiment switch (see rc_fused.hip, DIRECT)
+#else
+  int fused_direct = 0;
+#endif
   bool fused_ok = false;
   bool fused_front_ok = false;               // transient handles: the FRONT variant of the fused kernel is usable
   // hipGraph replay of the launch sequence (graph_mode: 0 off, 1 capture when a call repeats, 2 always)

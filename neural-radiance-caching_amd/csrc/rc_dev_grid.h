@@ -32,7 +32,7 @@ __device__ __forceinline__ Vec<F> load_entry(const float* __restrict__ table, ui
 #ifndef RC_DEV_CONTRACT3
 #define RC_DEV_CONTRACT3
 __device__ __forceinline__ void contract3(float& x, float& y, float& z, float radius) {
-  x = x / radius; y = y / radius; z = z / radius;
+  x = rc_div(x, radius); y = rc_div(y, radius); z = rc_div(z, radius);
   float mag = x * x + y * y + z * z;
   mag = fmaxf(1.0f, mag);
   const float scale = (2.0f * sqrtf(mag) - 1.0f) / mag;
@@ -56,7 +56,7 @@ template <int F> struct Corners { Vec<F> val[8]; float cw[3]; uint32_t zero_mask
 // `table` may differ per lane.  The per-axis terms of the index are computed once per level (two
 // candidates per axis), a corner then costs an xor/add, the address and the load.
 // x01 = (x - bbox_min) / (bbox_max - bbox_min) (grid_utils.py:820, 863)
-__device__ __forceinline__ float unit_box(float bbox, float x) { return (x - (-bbox)) / (bbox - (-bbox)); }
+__device__ __forceinline__ float unit_box(float bbox, float x) { return rc_div(x - (-bbox), bbox - (-bbox)); }
 
 // POW2: the caller guarantees power-of-two hash tables (mask != 0): no modulo path.
 // STRIDE: distance between consecutive entries in units of F floats (2 for the interleaved [density | appearance]

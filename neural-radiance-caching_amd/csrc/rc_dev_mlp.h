@@ -246,7 +246,7 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(
 #ifndef RC_DEV_CONTRACT3
 #define RC_DEV_CONTRACT3
 __device__ __forceinline__ void contract3(float& x, float& y, float& z, float radius) {
-  x = x / radius; y = y / radius; z = z / radius;
+  x = rc_div(x, radius); y = rc_div(y, radius); z = rc_div(z, radius);
   float mag = x * x + y * y + z * z;
   mag = fmaxf(1.0f, mag);
   const float scale = (2.0f * sqrtf(mag) - 1.0f) / mag;

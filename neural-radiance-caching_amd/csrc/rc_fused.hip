@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
   float mx, my, mz, t0, t1;
   mean_of(j, mx, my, mz, t0, t1);
   float cx = mx, cy = my, cz = mz;
-  const float zx = mx / a.contract_radius, zy = my / a.contract_radius, zz = mz / a.contract_radius;
+  const float zx = rc_div(mx, a.contract_radius), zy = rc_div(my, a.contract_radius), zz = rc_div(mz, a.contract_radius);
   contract3(cx, cy, cz, a.contract_radius);
   float* act = act_wave + lane;
   // (GRAD) d feature / d contracted coordinate of the density grid, 96 values per point, goes to LDS: element e of
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
         gzy = s * gw[1] + 2.0f * ds * gz_dot * zy;
         gzz = s * gw[2] + 2.0f * ds * gz_dot * zz;
       }
-      ngx = gzx / a.contract_radius; ngy = gzy / a.contract_radius; ngz = gzz / a.contract_radius;
+      ngx = rc_div(gzx, a.contract_radius); ngy = rc_div(gzy, a.contract_radius); ngz = rc_div(gzz, a.contract_radius);
       neg_normalize(ngx, ngy, ngz);
     } else if constexpr (!FRONT && !DIRECT) {
       // the stream is consumed strictly in order: step the ring over the unused backward fragments

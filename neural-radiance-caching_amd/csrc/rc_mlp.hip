@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
   float zx = 0.0f, zy = 0.0f, zz = 0.0f;   // x / radius
   if (valid) {
     const int64_t q = a.src ? (int64_t)a.src[p] : p, ms = a.src ? a.n_src : a.n;
-    zx = a.means[q] / a.contract_radius; zy = a.means[ms + q] / a.contract_radius; zz = a.means[2 * ms + q] / a.contract_radius;
+    zx = rc_div(a.means[q], a.contract_radius); zy = rc_div(a.means[ms + q], a.contract_radius); zz = rc_div(a.means[2 * ms + q], a.contract_radius);
     cx = a.means[q]; cy = a.means[ms + q]; cz = a.means[2 * ms + q];
     contract3(cx, cy, cz, a.contract_radius);
   }
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
         gzy = s * gw[1] + 2.0f * ds * gz_dot * zy;
         gzz = s * gw[2] + 2.0f * ds * gz_dot * zz;
       }
-      float nx = gzx / a.contract_radius, ny = gzy / a.contract_radius, nz = gzz / a.contract_radius;
+      float nx = rc_div(gzx, a.contract_radius), ny = rc_div(gzy, a.contract_radius), nz = rc_div(gzz, a.contract_radius);
       neg_normalize(nx, ny, nz);
       a.normals_grad[p] = nx; a.normals_grad[a.n + p] = ny; a.normals_grad[2 * a.n + p] = nz;
     }

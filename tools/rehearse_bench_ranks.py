@@ -18,7 +18,10 @@ def all_reduce(t, op=dist.ReduceOp.SUM, **kw):
 def all_gather(outs, t, **kw):
     co = [o.cpu() for o in outs]; _ag(co, t.cpu(), **kw)
     for o, c in zip(outs, co): o.copy_(c)
-dist.all_reduce, dist.all_gather = all_reduce, all_gather
+def all_gather_into_tensor(out, t, **kw):
+    co = list(out.cpu().chunk(dist.get_world_size())); _ag(co, t.cpu(), **kw)
+    out.copy_(torch.cat(co))
+dist.all_reduce, dist.all_gather, dist.all_gather_into_tensor = all_reduce, all_gather, all_gather_into_tensor
 sys.argv = ["bench.py", "--gpus", "2", "--steps", "24", "--warmup", "4", "--no-cpu-baseline"]
 runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
 '''.replace("ROOT", repr(ROOT))
@@ -34,4 +37,7 @@ for rank, (p, (o, e)) in enumerate(zip(procs, outs)):
 line = json.loads(outs[0][0].strip().splitlines()[-1])
 assert not any(l.startswith("{") for l in outs[1][0].splitlines()), "only rank 0 prints the JSON line: " + outs[1][0][:200]
 assert line["n_gpus"] == 2 and line["steps"] == 24 and line["scaling"] == "weak"
+img = line["image"]
+assert img["n_gpus"] == 2 and img["scaling"] == "strong" and img["ms_per_image"] > 0 and 0.3 < img["acc_mean"] < 1.0, img
+print("image line:", {k: img[k] for k in ("ms_per_image", "rays_per_s", "collective", "acc_mean")})
 print("rank 0 line:", {k: line[k] for k in ("metric", "value", "n_gpus", "steps", "warmup", "ms_per_step", "scaling")})
