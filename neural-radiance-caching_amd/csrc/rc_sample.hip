@@ -63,8 +63,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_sample_level(RcSampleAr
   const float logit = a.anneal * safe_log(w + a.padding);
   const bool hasj = a.jitter != nullptr;
   const float jit = hasj ? a.jitter[ray] : 0.0f;
-  __syncthreads();
-  sample_intervals_wave(logit, P, S, us, hasj, jit, s_t, s_cw, s_c, s_v, s_out, lane);
+  // every wave works on its own LDS slice: wave-local hand-offs, and the exact rank sort of jnp.sort only when the
+  // clipped fence posts really contain an inversion (same values as the unconditional sort)
+  lds_sync<false>();
+  sample_intervals_wave<false>(logit, P, S, us, hasj, jit, s_t, s_cw, s_c, s_v, s_out, lane);
 
   // --- s -> t (coord.py:259-260), cast (render.py:49-59, 106-131)
   float s_near = 0.0f, s_far = 0.0f;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_sample_level(RcSampleAr
       a.tdist[ray * (S + 1) + e2] = t;
     }
   }
-  __syncthreads();
+  lds_sync<false>();
   if (lane < S && ray_ok) {
     const float t0 = s_v[lane], t1 = s_v[lane + 1];
     const float sm = t0 + t1, d = t1 - t0;
