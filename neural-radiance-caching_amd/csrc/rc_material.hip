@@ -92,29 +92,41 @@ __global__ void k_gather_points(RcMatPointsArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Material head: grid features (32) -> Dense 128 -> Dense 10 -> microfacet parameters
 // ---------------------------------------------------------------------------------------------
+// One workgroup takes MH_PTS points: thread t keeps column t of the first layer in registers, so the 16 KB of w0 is
+// read once per MH_PTS points instead of once per point.  Sums run in the same order as the one-point form.
+constexpr int MH_PTS = 16;
 __global__ __launch_bounds__(128) void k_material_head(RcMatHeadArgs a) {
-  __shared__ float s_feat[32], s_b[128], s_out[10];
-  const int64_t p = blockIdx.x;
+  __shared__ float s_feat[MH_PTS][32], s_h[MH_PTS][128], s_out[MH_PTS][10];
+  const int64_t p0 = (int64_t)blockIdx.x * MH_PTS;
+  const int np = (int)((a.n - p0) < MH_PTS ? (a.n - p0) : MH_PTS);
   const int t = threadIdx.x;
-  if (t < 32) s_feat[t] = a.feat[p * 32 + t];
-  __syncthreads();
-  float acc = 0.0f;
+  for (int e = t; e < np * 32; e += 128) s_feat[e >> 5][e & 31] = a.feat[p0 * 32 + e];
+  float w[32];
 #pragma unroll
-  for (int i = 0; i < 32; ++i) acc = acc + s_feat[i] * a.w0[i * 128 + t];
-  s_b[t] = acc + a.b0[t];
+  for (int i = 0; i < 32; ++i) w[i] = a.w0[i * 128 + t];
+  const float b0 = a.b0[t];
   __syncthreads();
-  if (t < 10) {
-    float o = 0.0f;
-    for (int j = 0; j < 128; ++j) o = o + s_b[j] * a.w1[j * 10 + t];
-    s_out[t] = o + a.b1[t];
+  for (int q = 0; q < np; ++q) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc = acc + s_feat[q][i] * w[i];
+    s_h[q][t] = acc + b0;
   }
   __syncthreads();
-  if (t == 0) {
-    float* m = a.mat + p * RC_MAT_CH;
+  for (int e = t; e < np * 10; e += 128) {
+    const int q = e / 10, c = e - q * 10;
+    float o = 0.0f;
+    for (int j = 0; j < 128; ++j) o = o + s_h[q][j] * a.w1[j * 10 + c];
+    s_out[q][c] = o + a.b1[c];
+  }
+  __syncthreads();
+  if (t < np) {
+    float* m = a.mat + (p0 + t) * RC_MAT_CH;
+    const float* so = s_out[t];
     const float r0 = a.min_roughness * a.min_roughness;
-    m[0] = sigmoidf(s_out[0] - 1.0f); m[1] = sigmoidf(s_out[1] - 1.0f); m[2] = sigmoidf(s_out[2] - 1.0f);   // albedo
-    m[3] = sigmoidf(s_out[6] - 1.0f) * (1.0f - r0) + r0;                                                     // roughness
-    m[4] = sigmoidf(s_out[8] + 0.0f);                                                                        // metalness
+    m[0] = sigmoidf(so[0] - 1.0f); m[1] = sigmoidf(so[1] - 1.0f); m[2] = sigmoidf(so[2] - 1.0f);   // albedo
+    m[3] = sigmoidf(so[6] - 1.0f) * (1.0f - r0) + r0;                                               // roughness
+    m[4] = sigmoidf(so[8] + 0.0f);                                                                  // metalness
   }
 }
 
@@ -464,7 +476,7 @@ void rc_launch_gather_points(const RcMatPointsArgs& a, hipStream_t st) {
 }
 void rc_launch_material_head(const RcMatHeadArgs& a, hipStream_t st) {
   if (a.n <= 0) return;
-  hipLaunchKernelGGL(k_material_head, dim3((unsigned)a.n), dim3(128), 0, st, a);
+  hipLaunchKernelGGL(k_material_head, dim3((unsigned)((a.n + MH_PTS - 1) / MH_PTS)), dim3(128), 0, st, a);
 }
 void rc_launch_material_composite_all(int64_t n, int S, const float* weights, const float* mat, float* out_albedo,
                                       float* out_rough, float* out_metal, float* out_f0, float f0, hipStream_t st) {

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
   const float dx = a.directions[3 * ray], dy = a.directions[3 * ray + 1], dz = a.directions[3 * ray + 2];
   const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
   for (int e2 = lane; e2 <= S; e2 += 64) s_t[e2] = a.tdist[ray * (S + 1) + e2];
-  __syncthreads();
+  lds_sync<false>();
   const float t0 = act ? s_t[lane] : 1.0f, t1 = act ? s_t[lane + 1] : 1.0f;
   const float dens = act ? a.density[pidx] : 0.0f;
   const float wnf = alpha_weight(dens, t0, t1, dnorm, act, lane);     // weights_no_filter
@@ -208,30 +208,38 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
     if (lane == 0 && ray_ok && a.out.ptr[id]) a.out.ptr[id][ray] = x;
   };
 
+  // Every output is a handful of wave reductions: a slot the caller did not ask for (NULL) is skipped -- the batched
+  // secondary trace of the material stage asks for rgb and acc only.  The branches are uniform (kernel arguments).
+  auto want = [&](int id) { return a.out.ptr[id] != nullptr; };
   const float bgw = fmaxf(0.0f, 1.0f - acc) * a.bg;
-  float r[3], ad[3], idf[3], isp[3], tint[3], dif[3], ind[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float v_rgb = shade(RC_SH_RGB + c), v_ad = shade(RC_SH_AD + c), v_id = shade(RC_SH_ID + c);
-    const float v_is = shade(RC_SH_IS + c), v_t = shade(RC_SH_TINT + c);
-    r[c] = wave_sum(w * v_rgb) + bgw;
-    ad[c] = wave_sum(w * v_ad);
-    idf[c] = wave_sum(w * v_id);
-    isp[c] = wave_sum(w * v_is);
-    tint[c] = wave_sum(w * v_t);
-    dif[c] = wave_sum(w * (v_ad + v_id));       // diffuse_rgb = ambient_diffuse + indirect_diffuse
-    ind[c] = wave_sum(w * (v_id + v_is));       // indirect_rgb = indirect_diffuse + indirect_specular
+    // per channel: the sums are taken in the same order as before (each its own butterfly)
+    const bool w_rgb = want(RC_OUT_RGB), w_ad = want(RC_OUT_DIRECT_RGB), w_id = want(RC_OUT_INDIRECT_DIFFUSE_RGB);
+    const bool w_is = want(RC_OUT_INDIRECT_SPECULAR_RGB) || want(RC_OUT_SPECULAR_RGB), w_t = want(RC_OUT_ALBEDO_RGB);
+    const bool w_dif = want(RC_OUT_DIFFUSE_RGB), w_ind = want(RC_OUT_INDIRECT_RGB);
+    const float v_rgb = w_rgb ? shade(RC_SH_RGB + c) : 0.0f;
+    const float v_ad = (w_ad || w_dif) ? shade(RC_SH_AD + c) : 0.0f;
+    const float v_id = (w_id || w_dif || w_ind) ? shade(RC_SH_ID + c) : 0.0f;
+    const float v_is = (w_is || w_ind) ? shade(RC_SH_IS + c) : 0.0f;
+    const float v_t = w_t ? shade(RC_SH_TINT + c) : 0.0f;
+    auto put = [&](int id, float x) { if (lane == 0 && ray_ok && a.out.ptr[id]) a.out.ptr[id][3 * ray + c] = x; };
+    if (w_rgb) put(RC_OUT_RGB, wave_sum(w * v_rgb) + bgw);
+    if (w_ad) put(RC_OUT_DIRECT_RGB, wave_sum(w * v_ad));
+    if (w_id) put(RC_OUT_INDIRECT_DIFFUSE_RGB, wave_sum(w * v_id));
+    if (w_is) {
+      const float isp = wave_sum(w * v_is);
+      put(RC_OUT_INDIRECT_SPECULAR_RGB, isp);
+      put(RC_OUT_SPECULAR_RGB, isp);             // ambient_specular == 0 exactly
+    }
+    if (w_t) put(RC_OUT_ALBEDO_RGB, wave_sum(w * v_t));
+    if (w_dif) put(RC_OUT_DIFFUSE_RGB, wave_sum(w * (v_ad + v_id)));       // diffuse_rgb = ambient_diffuse + indirect_diffuse
+    if (w_ind) put(RC_OUT_INDIRECT_RGB, wave_sum(w * (v_id + v_is)));      // indirect_rgb = indirect_diffuse + indirect_specular
   }
-  store3(RC_OUT_RGB, r[0], r[1], r[2]);
-  store3(RC_OUT_DIRECT_RGB, ad[0], ad[1], ad[2]);
-  store3(RC_OUT_INDIRECT_DIFFUSE_RGB, idf[0], idf[1], idf[2]);
-  store3(RC_OUT_INDIRECT_SPECULAR_RGB, isp[0], isp[1], isp[2]);
-  store3(RC_OUT_SPECULAR_RGB, isp[0], isp[1], isp[2]);   // ambient_specular == 0 exactly
-  store3(RC_OUT_ALBEDO_RGB, tint[0], tint[1], tint[2]);
-  store3(RC_OUT_DIFFUSE_RGB, dif[0], dif[1], dif[2]);
-  store3(RC_OUT_INDIRECT_RGB, ind[0], ind[1], ind[2]);
-  const float wsum = wave_sum(contrib ? w : 0.0f);        // indirect_occ = sum w * 1
-  store3(RC_OUT_INDIRECT_OCC, wsum, wsum, wsum);
+  if (want(RC_OUT_INDIRECT_OCC)) {
+    const float wsum = wave_sum(contrib ? w : 0.0f);        // indirect_occ = sum w * 1
+    store3(RC_OUT_INDIRECT_OCC, wsum, wsum, wsum);
+  }
   store1(RC_OUT_ACC, acc);
 
   // geometry extras (always rendered: means, normals*, ray_dists, light_dists)
@@ -239,21 +247,23 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
     const float mx = act ? a.means[pidx] : 0.0f, my = act ? a.means[np + pidx] : 0.0f,
                 mz = act ? a.means[2 * np + pidx] : 0.0f;
     const float wc = contrib ? w : 0.0f;
-    store3(RC_OUT_MEANS, wave_sum(wc * mx), wave_sum(wc * my), wave_sum(wc * mz));
-    const float ox = a.origins[3 * ray], oy = a.origins[3 * ray + 1], oz = a.origins[3 * ray + 2];
-    const float rd = sqrtf((ox - mx) * (ox - mx) + (oy - my) * (oy - my) + (oz - mz) * (oz - mz));
-    store1(RC_OUT_RAY_DISTS, wave_sum(wc * rd));
-    if (a.lights) {
+    if (want(RC_OUT_MEANS)) store3(RC_OUT_MEANS, wave_sum(wc * mx), wave_sum(wc * my), wave_sum(wc * mz));
+    if (want(RC_OUT_RAY_DISTS)) {
+      const float ox = a.origins[3 * ray], oy = a.origins[3 * ray + 1], oz = a.origins[3 * ray + 2];
+      const float rd = sqrtf((ox - mx) * (ox - mx) + (oy - my) * (oy - my) + (oz - mz) * (oz - mz));
+      store1(RC_OUT_RAY_DISTS, wave_sum(wc * rd));
+    }
+    if (a.lights && want(RC_OUT_LIGHT_DISTS)) {
       const float lx = a.lights[3 * ray], ly = a.lights[3 * ray + 1], lz = a.lights[3 * ray + 2];
       const float ld = sqrtf((lx - mx) * (lx - mx) + (ly - my) * (ly - my) + (lz - mz) * (lz - mz));
       store1(RC_OUT_LIGHT_DISTS, wave_sum(wc * ld));
     }
-    if (a.normals_pred) {
+    if (a.normals_pred && want(RC_OUT_NORMALS_PRED)) {
       const float nx = act ? a.normals_pred[pidx] : 0.0f, ny = act ? a.normals_pred[np + pidx] : 0.0f,
                   nz = act ? a.normals_pred[2 * np + pidx] : 0.0f;
       store3(RC_OUT_NORMALS_PRED, wave_sum(wc * nx), wave_sum(wc * ny), wave_sum(wc * nz));
     }
-    if (a.normals_grad) {
+    if (a.normals_grad && want(RC_OUT_NORMALS)) {
       const float nx = act ? a.normals_grad[pidx] : 0.0f, ny = act ? a.normals_grad[np + pidx] : 0.0f,
                   nz = act ? a.normals_grad[2 * np + pidx] : 0.0f;
       store3(RC_OUT_NORMALS, wave_sum(wc * nx), wave_sum(wc * ny), wave_sum(wc * nz));
@@ -261,7 +271,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
   }
 
   // distances (render.py:227-245) always use weights_no_filter
-  {
+  if (want(RC_OUT_DISTANCE_MEAN) || want(RC_OUT_DISTANCE_PERCENTILE_5) || want(RC_OUT_DISTANCE_MEDIAN) ||
+      want(RC_OUT_DISTANCE_PERCENTILE_95)) {
     const float tmid = 0.5f * (t0 + t1);
     const float e = wave_sum(act ? wnf * logf(tmid) : 0.0f) / fmaxf(RC_EPS, acc);
     float dm = expf(e);
@@ -274,7 +285,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
     if (lane == 0) s_cw[0] = 0.0f;
     if (lane < S - 1) s_cw[lane + 1] = fminf(1.0f, incl);
     if (lane == 0) s_cw[S] = 1.0f;
-    __syncthreads();
+    lds_sync<false>();                           // this wave's own slice
     if (lane < 3 && ray_ok) {
       const float ps = a.pct[lane] / 100.0f;
       const float v = interp1(ps, s_cw, s_t, S + 1);
