@@ -176,6 +176,9 @@ def material_line(local_rank, dev, n_rays=1024, steps=5, warmup=2):
                vmf_v=torch.from_numpy(rng.normal(size=(n_rays, Kd - kc, 2)).astype(np.float32)).to(dev), vmf_tmp=u(n_rays, Kd - kc),
                spec_jitter=[u(n_rays * Ks) for _ in range(3)], spec_gumbel=g(n_rays * Ks, S),
                diff_jitter=[u(n_rays * Kd) for _ in range(3)], diff_gumbel=g(n_rays * Kd, S))
+    # the secondary trace's randoms in the ABI's own layout ([specular block | diffuse block], rc_abi.h rc_material_randoms)
+    rnd["sec_jitter"] = [torch.cat([rnd["spec_jitter"][l], rnd["diff_jitter"][l]]) for l in range(3)]
+    rnd["sec_gumbel"] = torch.cat([rnd["spec_gumbel"], rnd["diff_gumbel"]], dim=0).contiguous()
     for _ in range(warmup):
         rc.render_material(f, rnd)
     torch.cuda.synchronize()

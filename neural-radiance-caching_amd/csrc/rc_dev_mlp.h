@@ -36,8 +36,7 @@ struct WStream {
 };
 
 // Issue the LDS-DMA of chunk c (this wave's quarter: 4 x 1 KiB).
-// CH: fragments per chunk of this kernel's ring (kChunk unless LDS is short: the EnvMap kernel runs 4 waves with a
-// 2 x 8 KiB ring).
+// CH: fragments per chunk of this kernel's ring (kChunk by default; the EnvMap kernel runs a 2 x 8 KiB ring).
 template <int NF, int W = kWaves, int CH = kChunk>
 __device__ __forceinline__ void ws_issue(const WStream& w, int c) {
   static_assert(CH % (4 * W) == 0, "whole 1-KiB pieces per wave");
@@ -134,6 +133,19 @@ __device__ __forceinline__ void mlp_layer(const WS& w, const float* act, f32x16 
   }
 }
 
+
+// The bias k-step of a layer (fragments [FBASE, FBASE + NT): the bias row of each tile) with its B operand -- 1 on the
+// first half-wave, 0 on the second -- taken from a register instead of an activation slot: a 256-wide layer then needs
+// 128 activation steps in LDS, not 129.  Same MFMAs in the same order as a 129th step of mlp_layer.
+template <int NT, int FBASE, int NF, int W = kWaves, int CH = kChunk, class WS = WStream>
+__device__ __forceinline__ void mlp_bias_step(const WS& w, f32x16 (&acc)[NT]) {
+  const float one = w.lane < 32 ? 1.0f : 0.0f;
+  float a[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) a[t] = ws_read<NF, W, CH>(w, FBASE + t);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], one, acc[t], 0, 0, 0);
+}
 
 // Same as mlp_layer for PT point-tiles per wave (64 points): every A fragment read from the ring feeds
 // PT MFMAs.  Tile p's activation column starts at act + p * tile_stride.

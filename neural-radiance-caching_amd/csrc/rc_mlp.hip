@@ -235,11 +235,16 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_shader(RcShaderArgs a) {
 // -> concat input (283) -> 128 -> rgba; rgb = clip(softplus(raw + rgb_bias), 0, inf).
 // Replaces Model._handle_env_map -> SurfaceLightFieldMLP.__call__ as configured by
 // NeRFModel.env_map_params (internal/models.py:360-421, internal/surface_light_field.py:480-499,
-// 1011-1058, internal/coord.py:298-312).  One wave = 32 rays.  The 256-wide activations need 129 LDS steps per wave
-// (33 KiB): four waves (one per SIMD) fit next to a ring of 2 x 8 KiB chunks (149 KiB), not next to the usual 32 KiB one.
+// 1011-1058, internal/coord.py:298-312).  One wave = 32 rays.  The 256-wide activations take 128 LDS steps per wave
+// (32 KiB; the bias step of those layers takes its B operand from a register, mlp_bias_step): four waves (one per
+// SIMD) sit next to a ring of 2 x 8 KiB chunks (144 KiB; a ring of 16-KiB chunks measures the same).
+// The 256 -> 256 layers run as two 64-step halves: as ONE 128-step loop of 8 tiles the body exceeds the compiler's
+// full-unroll budget, the loop stays rolled, the three operand register sets turn into runtime-indexed registers
+// (s_set_gpr_idx) with one s_waitcnt per LDS read, and the kernel takes 160 us instead of 110 (tools/isa_scan.py
+// looks for exactly that).
 // ---------------------------------------------------------------------------------------------
 constexpr int kEnvWaves = 4;
-constexpr int kEnvActSteps = 130;
+constexpr int kEnvActSteps = 128;
 constexpr int kEnvChunk = 32;                        // fragments per chunk of this kernel's ring
 constexpr int kEnvRingFloats = 2 * kEnvChunk * 64;
 
@@ -279,14 +284,17 @@ __global__ __launch_bounds__(kEnvWaves * 64) void k_envmap(RcEnvMapArgs a) {
   for (int t = 0; t < 8; ++t) acc[t] = zero16();
   mlp_layer<8, KS_IN, F_E0, NF, 1, kEnvWaves, kEnvChunk>(ws, act, acc);
   park<8, true>(acc, act, 0);
-  act[128 * 64] = h == 0 ? 1.0f : 0.0f;
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = zero16();
-  mlp_layer<8, 129, F_E1, NF, 1, kEnvWaves, kEnvChunk>(ws, act, acc);
+  mlp_layer<8, 64, F_E1, NF, 1, kEnvWaves, kEnvChunk>(ws, act, acc);
+  mlp_layer<8, 64, F_E1 + 64 * 8, NF, 1, kEnvWaves, kEnvChunk>(ws, act + 64 * 64, acc);
+  mlp_bias_step<8, F_E1 + 128 * 8, NF, kEnvWaves, kEnvChunk>(ws, acc);
   park<8, true>(acc, act, 0);
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = zero16();
-  mlp_layer<8, 129, F_E2, NF, 1, kEnvWaves, kEnvChunk>(ws, act, acc);
+  mlp_layer<8, 64, F_E2, NF, 1, kEnvWaves, kEnvChunk>(ws, act, acc);
+  mlp_layer<8, 64, F_E2 + 64 * 8, NF, 1, kEnvWaves, kEnvChunk>(ws, act + 64 * 64, acc);
+  mlp_bias_step<8, F_E2 + 128 * 8, NF, kEnvWaves, kEnvChunk>(ws, acc);
   park<8, true>(acc, act, 0);
   // layer_bottleneck on concat([x2 (256), inputs (27)]): x part, then the re-staged input part (+bias)
   f32x16 bt[4];

@@ -712,11 +712,22 @@ class RadianceCache:
             held["m_lobe_g"] = self._dev(randoms["vmf_lobe_gumbel"]).reshape(n, -1)
             mr.vmf_lobe_gumbel = held["m_lobe_g"].data_ptr()
         # secondary trace randoms: [specular block | diffuse block]
+        # (a caller that keeps them in the ABI's layout passes sec_jitter[3] [n*K] / sec_gumbel [n*K, S] and skips the copies)
         for l in range(RC_MAX_LEVELS):
-            held[f"sj{l}"] = torch.cat([self._dev(randoms["spec_jitter"][l]).reshape(-1),
-                                        self._dev(randoms["diff_jitter"][l]).reshape(-1)])
+            if randoms.get("sec_jitter") is not None:
+                held[f"sj{l}"] = self._dev(randoms["sec_jitter"][l]).reshape(-1)
+                if held[f"sj{l}"].numel() != n * K:
+                    raise ValueError(f"sec_jitter[{l}]: expected {n * K} values")
+            else:
+                held[f"sj{l}"] = torch.cat([self._dev(randoms["spec_jitter"][l]).reshape(-1),
+                                            self._dev(randoms["diff_jitter"][l]).reshape(-1)])
             mr.sec_jitter[l] = held[f"sj{l}"].data_ptr()
-        if randoms.get("spec_gumbel") is not None and randoms.get("diff_gumbel") is not None:
+        if randoms.get("sec_gumbel") is not None:
+            held["sg"] = self._dev(randoms["sec_gumbel"])
+            if held["sg"].shape[0] != n * K:
+                raise ValueError(f"sec_gumbel: expected {n * K} rows")
+            mr.sec_gumbel = held["sg"].data_ptr()
+        elif randoms.get("spec_gumbel") is not None and randoms.get("diff_gumbel") is not None:
             held["sg"] = torch.cat([self._dev(randoms["spec_gumbel"]), self._dev(randoms["diff_gumbel"])], dim=0).contiguous()
             mr.sec_gumbel = held["sg"].data_ptr()
         # explicit categorical picks (filtered_sampler_inds) instead of the Gumbel draws
