@@ -223,6 +223,8 @@ __device__ __forceinline__ float eval_vmf(V3 x, V3 mean, float kappa) {
 __global__ __launch_bounds__(256) void k_brdf_sample(RcBrdfSampleArgs a) {
   __shared__ float s_vmf[4][128 * RC_VMF_CH];
   __shared__ float s_den[4][128];        // 4 pi sinh(kappa) per lobe: the direction-independent part of eval_vmf
+  __shared__ float s_qdir[4][128 * 3];   // query directions of the mixture pdf (at most 2 Kd <= 128 per point)
+  __shared__ float s_qpdf[4][128];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int64_t r = (int64_t)blockIdx.x * 4 + wave;
   const bool ok = r < a.n;
@@ -262,21 +264,18 @@ __global__ __launch_bounds__(256) void k_brdf_sample(RcBrdfSampleArgs a) {
   const Frame f = make_frame(nrm);
   const V3 lv = to_local(gview, f);
   const float alpha = a.mat[r * RC_MAT_CH + 3];
-  auto light_pdf = [&](V3 gdir) {
-    float s = 0.0f;
-    for (int j = 0; j < 128; ++j) {
-      const float* q = vm + j * RC_VMF_CH;
-      // eval_vmf with its denominator 4 pi sinh(kappa) taken from the per-lobe table (same operations, same order)
-      const float kappa = q[3];
-      const float e = kappa <= RC_EPS ? 1.0f / (4.0f * kPi)
-                                      : kappa * expf(fminf(kappa * dot(gdir, V3{q[0], q[1], q[2]}), 80.0f)) / den[j];
-      s = s + q[4] * e;
-    }
-    return fmaxf(s, 0.0f);
-  };
-  if (lane < K && ok) {
-    V3 ld;       // local light direction
-    float pdf, weight;
+  // Mixture pdf of the 128 lobes at a direction: the (direction, lobe) terms of ALL the point's queries are spread over
+  // the wave -- every lane takes lobes lane and lane + 64 of each query, a butterfly adds them up -- instead of each
+  // diffuse lane walking the 128 lobes once or twice by itself.  Queries: [0, Kd) the MIS light pdf at each diffuse
+  // sample's direction, [Kd, Kd + Kl) the sampling pdf of each vMF sample.
+  float* qdir = s_qdir[wave];
+  float* qpdf = s_qpdf[wave];
+  V3 ld = {0.0f, 0.0f, 1.0f};
+  float pdf = 0.0f, weight = 0.0f, own_pdf = 0.0f;
+  const bool live = lane < K && ok, diffuse = live && lane >= Ks;
+  const int kd = lane - Ks, kl = kd - Kc, Kl = Kd - Kc;
+  const bool vmf_lane = diffuse && kd >= Kc;
+  if (live) {
     if (lane < Ks) {
       // MicrofacetSampler.sample_directions (render_utils.py:501-531); single sampler -> weight 1
       const float u1 = a.spec_u1[r * Ks + lane], u2 = a.spec_u2[r * Ks + lane];
@@ -294,8 +293,6 @@ __global__ __launch_bounds__(256) void k_brdf_sample(RcBrdfSampleArgs a) {
       ld = ir_normalize(d);
       weight = 1.0f;
     } else {
-      const int kd = lane - Ks;
-      float own_pdf;
       if (kd < Kc) {
         // CosineSampler (render_utils.py:425-433)
         const float u1 = a.cos_u1[r * Kc + kd], u2 = a.cos_u2[r * Kc + kd];
@@ -306,7 +303,6 @@ __global__ __launch_bounds__(256) void k_brdf_sample(RcBrdfSampleArgs a) {
         own_pdf = fmaxf(z / kPi, 0.0f);
       } else {
         // LightSampler -> sample_vmf (render_utils.py:1390-1428): all directions from ONE lobe per point
-        const int kl = kd - Kc, Kl = Kd - Kc;
         const float* q = vm + lobe * RC_VMF_CH;
         const V3 mean = {q[0], q[1], q[2]};
         const float kappa = q[3];
@@ -325,15 +321,45 @@ __global__ __launch_bounds__(256) void k_brdf_sample(RcBrdfSampleArgs a) {
         // rotmat = stack([t, b, mean], axis=-1) @ loc
         const V3 g = {tv.x * loc.x + bv.x * loc.y + mean.x * loc.z, tv.y * loc.x + bv.y * loc.y + mean.y * loc.z,
                       tv.z * loc.x + bv.z * loc.y + mean.z * loc.z};
-        own_pdf = light_pdf(g);
+        qdir[3 * (Kd + kl)] = g.x; qdir[3 * (Kd + kl) + 1] = g.y; qdir[3 * (Kd + kl) + 2] = g.z;
         ld = to_local(g, f);
       }
-      // power heuristic over (cosine, light), one unit of each (render_utils.py:817-853)
       const V3 gl = to_global(ld, f);
+      qdir[3 * kd] = gl.x; qdir[3 * kd + 1] = gl.y; qdir[3 * kd + 2] = gl.z;
+    }
+  }
+  __syncthreads();
+  {
+    // eval_vmf (render_utils.py:1335-1355) with its denominator 4 pi sinh(kappa) from the per-lobe table
+    float m[2][3], kap[2], wgt[2], dn[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float* v = vm + (lane + 64 * q) * RC_VMF_CH;
+      m[q][0] = v[0]; m[q][1] = v[1]; m[q][2] = v[2]; kap[q] = v[3]; wgt[q] = v[4]; dn[q] = den[lane + 64 * q];
+    }
+    const int NQ = ok ? Kd + Kl : 0;
+    for (int qi = 0; qi < NQ; ++qi) {
+      const V3 gd = {qdir[3 * qi], qdir[3 * qi + 1], qdir[3 * qi + 2]};
+      float sacc = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float e = kap[q] <= RC_EPS ? 1.0f / (4.0f * kPi)
+                                         : kap[q] * expf(fminf(kap[q] * dot(gd, V3{m[q][0], m[q][1], m[q][2]}), 80.0f)) / dn[q];
+        sacc = sacc + wgt[q] * e;
+      }
+      sacc = wsum(sacc);
+      if (lane == 0) qpdf[qi] = fmaxf(sacc, 0.0f);
+    }
+  }
+  __syncthreads();
+  if (live) {
+    if (diffuse) {
+      // power heuristic over (cosine, light), one unit of each (render_utils.py:817-853)
+      if (vmf_lane) own_pdf = qpdf[Kd + kl];
       float pc = ld.z / kPi;
       if (ld.z < 0.0f) pc = 0.0f;
       pc = fmaxf(pc, 0.0f);
-      const float pl = light_pdf(gl);
+      const float pl = qpdf[kd];
       const float denom = fmaxf(pc * pc + pl * pl, kDenomEps);
       pdf = fmaxf(own_pdf, 0.0f);
       weight = (pdf * pdf) / denom * 2.0f;
