@@ -1070,6 +1070,7 @@ struct RenderArgs {
   rc_rays rays; rc_randoms rnd; bool have_rnd; int64_t n; uint32_t mask; rc_outputs out; int slot; bool fused;
   const rc_transient_outputs* tout = nullptr; const float* cam_origins = nullptr;
   const rc_randoms* shadow_rnd = nullptr; bool weights_only = false; bool force_grad = false;
+  bool export_samples = false;     // fused plan: leave tdist / density / means / normals_pred of the last level in the workspace
 };
 
 void enqueue_transient_tail(rc_handle* h, const RenderArgs& A, hipStream_t st);
@@ -1104,6 +1105,12 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     F.rgb_max = c.rgb_max; F.slf_ambient_bias = c.slf_ambient_bias;
     F.out = A.out;
     F.direct = h->fused_direct;
+    if (A.export_samples) {
+      const std::string L2 = std::to_string(NL - 1);
+      F.export_samples = 1;
+      F.f_tdist = W(h, "tdist" + L2); F.f_density = W(h, "density" + L2); F.f_means = W(h, "means" + L2);
+      F.f_normals_pred = W(h, "normals_pred");
+    }
     // profiling: the single launch is reported as the "shader" stage, every other stage as 0
     for (int i = 0; i <= ST_SHADER; ++i) stage_mark(h, slot, i, st);
     rc_launch_fused(F, st);
@@ -1522,6 +1529,10 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
   RenderArgs A{};
   A.rays = *rays; A.have_rnd = rnd != nullptr; if (rnd) A.rnd = *rnd;
   A.n = n; A.mask = RC_PASS_CACHE; A.out = *cache_out; A.slot = -1;
+  // the fused kernel when the handle runs it (rc_set_fused mode 1): one launch, its per-sample results exported for
+  // steps 2-3 below; bitwise the launch-per-stage pass (tests/test_gpu_parity.py)
+  A.fused = h->fused_mode == 1 && h->fused_ok && !h->profiling && c.num_samples[NL - 1] == 32;
+  A.export_samples = A.fused;
   enqueue_all(h, A, st);
 
   // 2. one shading sample per ray (MaterialModel.resample_render, models.py:1430-1439)

@@ -117,7 +117,10 @@ struct RcFusedArgs {
 // phases stop queueing behind each other in the CU's memory pipe.  Bitwise equal results; measured 145 us per 1024 rays
 // against 132 us through the ring: 2165 extra vector loads per ray and their L2 latency cost more than the 40 barriers
 // and the lockstep.  Kept as a template parameter, not instantiated in the product build.
-template <bool GRAD, bool FRONT = false, bool DIRECT = false>
+// EXPORT: the full kernel that also leaves the last level's per-sample results (fence posts, density, sample means,
+// predicted normals) in the workspace buffers of the launch-per-stage plan, for a caller that goes on working per sample
+// behind the cache pass (the material stage: its shading-point pick and the material-only composite).
+template <bool GRAD, bool FRONT = false, bool DIRECT = false, bool EXPORT = false>
 __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
   constexpr int NF = FRONT ? F_SH : NF_FUSED;
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
@@ -435,6 +438,17 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
     }
     return;
   }
+  if constexpr (EXPORT) {
+    if (ray_ok) {
+      const int64_t np = a.n * 32, p = ray * 32 + j;
+      for (int e2 = lane; e2 <= 32; e2 += 64) a.f_tdist[ray * 33 + e2] = s_td[e2];
+      if (h == 0) {
+        a.f_density[p] = density;
+        a.f_means[p] = mx; a.f_means[np + p] = my; a.f_means[2 * np + p] = mz;
+        a.f_normals_pred[p] = npx; a.f_normals_pred[np + p] = npy; a.f_normals_pred[2 * np + p] = npz;
+      }
+    }
+  }
   // ------------------------------------------------------------------ shader on the 32 samples
 #pragma unroll
   for (int s = 0; s < 16; ++s) act[(32 + s) * 64] = act[(kAppTmp + s) * 64];
@@ -575,6 +589,8 @@ void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 #ifdef RC_FUSED_DIRECT_EXPERIMENT
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -609,6 +625,12 @@ void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream) {
     a.f_normals_grad = L.want_grad ? L.f_normals_grad : nullptr; a.f_hbuf = L.f_hbuf; a.f_app = L.f_app;
     if (L.want_grad) hipLaunchKernelGGL((k_cache_fused<true, true>), grid, block, lds, stream, a);
     else hipLaunchKernelGGL((k_cache_fused<false, true>), grid, block, lds, stream, a);
+    return;
+  }
+  if (L.export_samples) {
+    a.f_tdist = L.f_tdist; a.f_density = L.f_density; a.f_means = L.f_means; a.f_normals_pred = L.f_normals_pred;
+    if (L.out.ptr[RC_OUT_NORMALS]) hipLaunchKernelGGL((k_cache_fused<true, false, false, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((k_cache_fused<false, false, false, true>), grid, block, lds, stream, a);
     return;
   }
 #ifdef RC_FUSED_DIRECT_EXPERIMENT      // measured 145.3 us against 132.2 us through the ring (same box, bitwise equal results): not built by default

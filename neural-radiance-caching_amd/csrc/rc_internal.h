@@ -259,6 +259,7 @@ struct RcFusedLaunch {
   // front end only (time-resolved cache): stop behind the last proposal level, results into the workspace buffers of
   // the launch-per-stage plan (wstream then ends at the shader's offset)
   int32_t front, want_grad;
+  int32_t export_samples;              // full kernel + f_tdist / f_density / f_means / f_normals_pred of the last level
   int32_t direct;                      // weight fragments straight from global memory (no LDS ring, no workgroup barriers)
   int32_t use_raydist; float raydist_p, raydist_premult;
   float* f_tdist; float* f_density; float* f_means; float* f_normals_pred; float* f_normals_grad; float* f_hbuf; float* f_app;

@@ -175,3 +175,33 @@ def test_level_kernels_equal_the_separate_gather_and_mlp_kernels(n):
         for k in res[0]:
             assert torch.equal(res[0][k].cpu(), res[2][k].cpu()), (mask, k)
     rc.set_fused(1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3, 130])
+def test_material_stage_is_bitwise_the_same_on_every_launch_plan(n):
+    """rc_render_material on the three launch plans of rc_set_fused: 1 (default) runs the primary cache pass as the ONE
+    fused launch with its per-sample results exported for the shading-point pick, 2 the launch-per-stage pass with the
+    level kernels, 0 one kernel per stage.  Every cache and material output, the picks and the secondary radiance are
+    bitwise equal."""
+    from oracle import material_ref
+    from nrc_amd import rc_ext
+    cfg = nrc_amd.hotdog_config()
+    rc = rc_ext.RadianceCache(cfg, 0)
+    rc.load_weights(common.weights_material_np(False))
+    rays = nrc_amd.synthetic_rays(n, seed=5)
+    rnd = material_ref.draw_randoms(cfg, n, seed=8)
+    res = {}
+    for mode in (0, 2, 1):
+        rc.set_fused(mode)
+        cres, mres = rc.render_material(rays.hot_fields(), rnd)
+        torch.cuda.synchronize()
+        res[mode] = {"c:" + k: v.clone() for k, v in cres.items()}
+        res[mode].update({"m:" + k: v.clone() for k, v in mres.items()})
+        res[mode]["inds"] = torch.from_numpy(rc.workspace("inds", np.int32)[:n].copy())
+        res[mode]["s:inds"] = torch.from_numpy(rc.workspace("s:inds", np.int32)[: n * 32].copy())
+        res[mode]["sec_rgb"] = torch.from_numpy(rc.workspace("sec_rgb")[: n * 96].copy())
+        res[mode]["weights2"] = torch.from_numpy(rc.workspace("weights2")[: n * 32].copy())
+    for mode in (2, 1):
+        for k in res[0]:
+            assert torch.equal(res[0][k].cpu(), res[mode][k].cpu()), (mode, k)
