@@ -148,7 +148,7 @@ def transient_line(local_rank, dev, n_rays=1024, steps=20, warmup=3):
             "note": "output allocation (3 x [1024,700,3] fp32 zero-fills) is inside the step"}
 
 
-def material_line(local_rank, dev, n_rays=1024, steps=5, warmup=2):
+def material_line(local_rank, dev, n_rays=1024, steps=20, warmup=3):
     """Secondary measurement (not part of `value`): rc_render_material on 1024 synthetic hotdog rays =
     material / light heads, 32 importance-sampled secondary rays per primary ray traced through the cache
     (32 768 secondary rays per step), Monte-Carlo BRDF integration (BASELINE configs[2])."""

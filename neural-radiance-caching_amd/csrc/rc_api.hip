@@ -126,6 +126,10 @@ struct rc_handle {
   // hipGraph replay of the launch sequence (graph_mode: 0 off, 1 capture when a call repeats, 2 always)
   int graph_mode = 1;
   hipStream_t cap_stream = nullptr;
+  // rc_render_material: work that the secondary trace does not wait for (material-only composite over all samples,
+  // EnvMap along the secondary rays) runs on this stream, forked from / joined to the caller's with events
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_side[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<GraphEntry> graphs;
   RenderKey last_key{};
   bool have_last_key = false;
@@ -877,6 +881,8 @@ void rc_destroy(rc_handle* h) {
   drop_graphs(h);
   for (auto& G : h->groups) if (G.done) (void)hipEventDestroy(G.done);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+  for (hipEvent_t e : h->ev_side) if (e) (void)hipEventDestroy(e);
   if (h->ev_created)
     for (int s = 0; s < kEvSlots; ++s)
       for (int i = 0; i <= ST_COUNT; ++i) (void)hipEventDestroy(h->ev[s][i]);
@@ -1550,32 +1556,44 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     rc_launch_gather_points(pa, st);
   }
   auto raw = [&](const char* path, const char* leaf) { return h->packs[std::string("raw:") + path + "/" + leaf].p; };
-  // 3. material head at the shading point, and on all samples for the material-only composite
+  // Side stream: the material-only composite over all samples (step 3b) and the EnvMap along the secondary rays (step 6b)
+  // feed only the outputs / the final integration, so they leave the critical path sampler -> trace -> integrate and
+  // fill the gaps of its latency-bound kernels.  Forked from and joined to the caller's stream with events: to the
+  // caller the call is still ordered on `st` alone.
+  if (!h->side_stream) {
+    RC_HIP(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    for (hipEvent_t& e : h->ev_side) RC_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  hipStream_t side = h->side_stream;
+  // 3a. material head at the shading point (caller's stream) | 4. light sampler: 128 vMF lobes per shading point (side
+  // stream) -- both read only the shading point; then 3b. the material head on all samples and the material-only
+  // composite (side stream)
   {
     RcMatHeadArgs ma{};
     ma.w0 = raw("params/MaterialShader/bottleneck_layer", "kernel"); ma.b0 = raw("params/MaterialShader/bottleneck_layer", "bias");
     ma.w1 = raw("params/MaterialShader/pred_brdf_layer", "kernel"); ma.b1 = raw("params/MaterialShader/pred_brdf_layer", "bias");
     ma.min_roughness = c.min_roughness;
-    rc_launch_hashgrid(h->grids[4].dev, W(h, "m_pts"), 0, n, W(h, "m_feat"), 0, 32, c.contract_radius, nullptr, st);
-    ma.n = n; ma.feat = W(h, "m_feat"); ma.mat = W(h, "m_mat");
-    rc_launch_material_head(ma, st);
-    rc_launch_hashgrid(h->grids[4].dev, W(h, "means" + LL), 1, np2, W(h, "m_feat_all"), 0, 32, c.contract_radius, nullptr, st);
-    ma.n = np2; ma.feat = W(h, "m_feat_all"); ma.mat = W(h, "m_mat_all");
-    rc_launch_material_head(ma, st);
-    rc_launch_material_composite_all(n, S2, W(h, "weights" + LL), W(h, "m_mat_all"), mat_out->ptr[RC_MOUT_MATERIAL_ALBEDO],
-                                     mat_out->ptr[RC_MOUT_MATERIAL_ROUGHNESS], mat_out->ptr[RC_MOUT_MATERIAL_METALNESS],
-                                     mat_out->ptr[RC_MOUT_MATERIAL_F_0], c.default_F_0, st);
-  }
-  // 4. light sampler: 128 vMF lobes per shading point
-  {
-    rc_launch_hashgrid(h->grids[5].dev, W(h, "m_pts"), 0, n, W(h, "l_feat"), 0, 32, c.contract_radius, nullptr, st);
+    RC_HIP(h, hipEventRecord(h->ev_side[0], st));                 // shading points, means / weights of the last level are in place
+    RC_HIP(h, hipStreamWaitEvent(side, h->ev_side[0], 0));
+    rc_launch_hashgrid(h->grids[5].dev, W(h, "m_pts"), 0, n, W(h, "l_feat"), 0, 32, c.contract_radius, nullptr, side);
     RcLightHeadArgs la{};
     la.n = n; la.feat = W(h, "l_feat");
     la.w0 = raw("params/LightSampler/layers_0", "kernel"); la.b0 = raw("params/LightSampler/layers_0", "bias");
     la.w1 = raw("params/LightSampler/layers_1", "kernel"); la.b1 = raw("params/LightSampler/layers_1", "bias");
     la.w2 = raw("params/LightSampler/output_layer", "kernel"); la.b2 = raw("params/LightSampler/output_layer", "bias");
     la.pts = W(h, "m_pts"); la.noise = mr->vmf_noise; la.vmf_scale = c.vmf_scale; la.vmf = W(h, "l_vmf");
-    rc_launch_light_head(la, st);
+    rc_launch_light_head(la, side);
+    RC_HIP(h, hipEventRecord(h->ev_side[3], side));
+    rc_launch_hashgrid(h->grids[4].dev, W(h, "means" + LL), 1, np2, W(h, "m_feat_all"), 0, 32, c.contract_radius, nullptr, side);
+    ma.n = np2; ma.feat = W(h, "m_feat_all"); ma.mat = W(h, "m_mat_all");
+    rc_launch_material_head(ma, side);
+    rc_launch_material_composite_all(n, S2, W(h, "weights" + LL), W(h, "m_mat_all"), mat_out->ptr[RC_MOUT_MATERIAL_ALBEDO],
+                                     mat_out->ptr[RC_MOUT_MATERIAL_ROUGHNESS], mat_out->ptr[RC_MOUT_MATERIAL_METALNESS],
+                                     mat_out->ptr[RC_MOUT_MATERIAL_F_0], c.default_F_0, side);
+    rc_launch_hashgrid(h->grids[4].dev, W(h, "m_pts"), 0, n, W(h, "m_feat"), 0, 32, c.contract_radius, nullptr, st);
+    ma.n = n; ma.feat = W(h, "m_feat"); ma.mat = W(h, "m_mat");
+    rc_launch_material_head(ma, st);
+    RC_HIP(h, hipStreamWaitEvent(st, h->ev_side[3], 0));          // the lobes
   }
   // 5. BRDF importance sampling -> secondary rays
   {
@@ -1604,12 +1622,19 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     memset(&B.out, 0, sizeof(B.out));
     B.out.ptr[RC_OUT_RGB] = W(h, "sec_rgb"); B.out.ptr[RC_OUT_ACC] = W(h, "sec_acc");
     float* sec_dirs = W(h, "sec_dirs"); float* sec_env = W(h, "sec_env");
+    // 6b. EnvMap of the secondary directions on the side stream, beside the first sampling kernel of the trace.
+    // (Released behind the last proposal level instead, it overlaps the pick and the per-pick lookups but holds the
+    // LDS the per-pick density MLP and the shader wait for: measured the same within noise.)
+    RC_HIP(h, hipEventRecord(h->ev_side[1], st));                 // secondary rays are in place
+    RC_HIP(h, hipStreamWaitEvent(side, h->ev_side[1], 0));
+    RcEnvMapArgs ea{};
+    ea.n = nsec; ea.viewdirs = sec_dirs; ea.wstream = h->packs["envmap"].p; ea.rgb_bias = c.env_rgb_bias; ea.env_rgb = sec_env;
+    rc_launch_envmap(ea, side);
+    RC_HIP(h, hipEventRecord(h->ev_side[2], side));
     h->ws_prefix = "s:";
     enqueue_all(h, B, st);
     h->ws_prefix = "";
-    RcEnvMapArgs ea{};
-    ea.n = nsec; ea.viewdirs = sec_dirs; ea.wstream = h->packs["envmap"].p; ea.rgb_bias = c.env_rgb_bias; ea.env_rgb = sec_env;
-    rc_launch_envmap(ea, st);
+    RC_HIP(h, hipStreamWaitEvent(st, h->ev_side[2], 0));          // join: everything of this call is ordered on st again
   }
   // 7. Monte-Carlo BRDF integration + MaterialIntegrator composite
   {
