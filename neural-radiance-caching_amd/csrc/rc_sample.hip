@@ -208,56 +208,75 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
     if (lane == 0 && ray_ok && a.out.ptr[id]) a.out.ptr[id][ray] = x;
   };
 
-  // Every output is a handful of wave reductions: a slot the caller did not ask for (NULL) is skipped -- the batched
-  // secondary trace of the material stage asks for rgb and acc only.  The branches are uniform (kernel arguments).
+  // Every output is a wave reduction.  A caller that asks for the colour components (the plain cache pass) gets all of
+  // them from ONE batched butterfly (the exchanges of the 33 sums in flight together); a caller that asks for rgb / acc
+  // and perhaps a geometry extra (the batched secondary trace of the material stage) runs only those reductions.  Either
+  // way each sum is added up in the same order: same bits.  The branches are uniform (kernel arguments).
   auto want = [&](int id) { return a.out.ptr[id] != nullptr; };
   const float bgw = fmaxf(0.0f, 1.0f - acc) * a.bg;
+  const float wc = contrib ? w : 0.0f;
+  const float mx = act ? a.means[pidx] : 0.0f, my = act ? a.means[np + pidx] : 0.0f, mz = act ? a.means[2 * np + pidx] : 0.0f;
+  auto ray_dist = [&]() {
+    const float ox = a.origins[3 * ray], oy = a.origins[3 * ray + 1], oz = a.origins[3 * ray + 2];
+    return sqrtf((ox - mx) * (ox - mx) + (oy - my) * (oy - my) + (oz - mz) * (oz - mz));
+  };
+  auto light_dist = [&]() {
+    const float lx = a.lights[3 * ray], ly = a.lights[3 * ray + 1], lz = a.lights[3 * ray + 2];
+    return sqrtf((lx - mx) * (lx - mx) + (ly - my) * (ly - my) + (lz - mz) * (lz - mz));
+  };
+  const bool components = want(RC_OUT_DIRECT_RGB) || want(RC_OUT_INDIRECT_DIFFUSE_RGB) || want(RC_OUT_INDIRECT_SPECULAR_RGB) ||
+                          want(RC_OUT_SPECULAR_RGB) || want(RC_OUT_ALBEDO_RGB) || want(RC_OUT_DIFFUSE_RGB) || want(RC_OUT_INDIRECT_RGB);
+  if (components) {
+    enum { V_RGB = 0, V_AD = 3, V_IDF = 6, V_IS = 9, V_TINT = 12, V_DIF = 15, V_IND = 18, V_OCC = 21, V_MEAN = 22, V_RD = 25,
+           V_LD = 26, V_NP = 27, V_NG = 30, V_COUNT = 33 };
+    float v[V_COUNT];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    // per channel: the sums are taken in the same order as before (each its own butterfly)
-    const bool w_rgb = want(RC_OUT_RGB), w_ad = want(RC_OUT_DIRECT_RGB), w_id = want(RC_OUT_INDIRECT_DIFFUSE_RGB);
-    const bool w_is = want(RC_OUT_INDIRECT_SPECULAR_RGB) || want(RC_OUT_SPECULAR_RGB), w_t = want(RC_OUT_ALBEDO_RGB);
-    const bool w_dif = want(RC_OUT_DIFFUSE_RGB), w_ind = want(RC_OUT_INDIRECT_RGB);
-    const float v_rgb = w_rgb ? shade(RC_SH_RGB + c) : 0.0f;
-    const float v_ad = (w_ad || w_dif) ? shade(RC_SH_AD + c) : 0.0f;
-    const float v_id = (w_id || w_dif || w_ind) ? shade(RC_SH_ID + c) : 0.0f;
-    const float v_is = (w_is || w_ind) ? shade(RC_SH_IS + c) : 0.0f;
-    const float v_t = w_t ? shade(RC_SH_TINT + c) : 0.0f;
-    auto put = [&](int id, float x) { if (lane == 0 && ray_ok && a.out.ptr[id]) a.out.ptr[id][3 * ray + c] = x; };
-    if (w_rgb) put(RC_OUT_RGB, wave_sum(w * v_rgb) + bgw);
-    if (w_ad) put(RC_OUT_DIRECT_RGB, wave_sum(w * v_ad));
-    if (w_id) put(RC_OUT_INDIRECT_DIFFUSE_RGB, wave_sum(w * v_id));
-    if (w_is) {
-      const float isp = wave_sum(w * v_is);
-      put(RC_OUT_INDIRECT_SPECULAR_RGB, isp);
-      put(RC_OUT_SPECULAR_RGB, isp);             // ambient_specular == 0 exactly
+    for (int c = 0; c < 3; ++c) {
+      const float v_rgb = shade(RC_SH_RGB + c), v_ad = shade(RC_SH_AD + c), v_id = shade(RC_SH_ID + c);
+      const float v_is = shade(RC_SH_IS + c), v_t = shade(RC_SH_TINT + c);
+      v[V_RGB + c] = w * v_rgb;
+      v[V_AD + c] = w * v_ad;
+      v[V_IDF + c] = w * v_id;
+      v[V_IS + c] = w * v_is;
+      v[V_TINT + c] = w * v_t;
+      v[V_DIF + c] = w * (v_ad + v_id);       // diffuse_rgb = ambient_diffuse + indirect_diffuse
+      v[V_IND + c] = w * (v_id + v_is);       // indirect_rgb = indirect_diffuse + indirect_specular
     }
-    if (w_t) put(RC_OUT_ALBEDO_RGB, wave_sum(w * v_t));
-    if (w_dif) put(RC_OUT_DIFFUSE_RGB, wave_sum(w * (v_ad + v_id)));       // diffuse_rgb = ambient_diffuse + indirect_diffuse
-    if (w_ind) put(RC_OUT_INDIRECT_RGB, wave_sum(w * (v_id + v_is)));      // indirect_rgb = indirect_diffuse + indirect_specular
-  }
-  if (want(RC_OUT_INDIRECT_OCC)) {
-    const float wsum = wave_sum(contrib ? w : 0.0f);        // indirect_occ = sum w * 1
-    store3(RC_OUT_INDIRECT_OCC, wsum, wsum, wsum);
-  }
-  store1(RC_OUT_ACC, acc);
-
-  // geometry extras (always rendered: means, normals*, ray_dists, light_dists)
-  {
-    const float mx = act ? a.means[pidx] : 0.0f, my = act ? a.means[np + pidx] : 0.0f,
-                mz = act ? a.means[2 * np + pidx] : 0.0f;
-    const float wc = contrib ? w : 0.0f;
+    v[V_OCC] = wc;                             // indirect_occ = sum w * 1
+    v[V_MEAN] = wc * mx; v[V_MEAN + 1] = wc * my; v[V_MEAN + 2] = wc * mz;
+    v[V_RD] = wc * ray_dist();
+    v[V_LD] = a.lights ? wc * light_dist() : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      v[V_NP + c] = a.normals_pred ? wc * (act ? a.normals_pred[c * np + pidx] : 0.0f) : 0.0f;
+      v[V_NG + c] = a.normals_grad ? wc * (act ? a.normals_grad[c * np + pidx] : 0.0f) : 0.0f;
+    }
+    wave_sum_n<V_COUNT>(v);
+    store3(RC_OUT_RGB, v[V_RGB] + bgw, v[V_RGB + 1] + bgw, v[V_RGB + 2] + bgw);
+    store3(RC_OUT_DIRECT_RGB, v[V_AD], v[V_AD + 1], v[V_AD + 2]);
+    store3(RC_OUT_INDIRECT_DIFFUSE_RGB, v[V_IDF], v[V_IDF + 1], v[V_IDF + 2]);
+    store3(RC_OUT_INDIRECT_SPECULAR_RGB, v[V_IS], v[V_IS + 1], v[V_IS + 2]);
+    store3(RC_OUT_SPECULAR_RGB, v[V_IS], v[V_IS + 1], v[V_IS + 2]);             // ambient_specular == 0 exactly
+    store3(RC_OUT_ALBEDO_RGB, v[V_TINT], v[V_TINT + 1], v[V_TINT + 2]);
+    store3(RC_OUT_DIFFUSE_RGB, v[V_DIF], v[V_DIF + 1], v[V_DIF + 2]);
+    store3(RC_OUT_INDIRECT_RGB, v[V_IND], v[V_IND + 1], v[V_IND + 2]);
+    store3(RC_OUT_INDIRECT_OCC, v[V_OCC], v[V_OCC], v[V_OCC]);
+    store3(RC_OUT_MEANS, v[V_MEAN], v[V_MEAN + 1], v[V_MEAN + 2]);
+    store1(RC_OUT_RAY_DISTS, v[V_RD]);
+    if (a.lights) store1(RC_OUT_LIGHT_DISTS, v[V_LD]);
+    if (a.normals_pred) store3(RC_OUT_NORMALS_PRED, v[V_NP], v[V_NP + 1], v[V_NP + 2]);
+    if (a.normals_grad) store3(RC_OUT_NORMALS, v[V_NG], v[V_NG + 1], v[V_NG + 2]);
+  } else {
+    if (want(RC_OUT_RGB))
+      store3(RC_OUT_RGB, wave_sum(w * shade(RC_SH_RGB)) + bgw, wave_sum(w * shade(RC_SH_RGB + 1)) + bgw,
+             wave_sum(w * shade(RC_SH_RGB + 2)) + bgw);
+    if (want(RC_OUT_INDIRECT_OCC)) {
+      const float wsum = wave_sum(wc);
+      store3(RC_OUT_INDIRECT_OCC, wsum, wsum, wsum);
+    }
     if (want(RC_OUT_MEANS)) store3(RC_OUT_MEANS, wave_sum(wc * mx), wave_sum(wc * my), wave_sum(wc * mz));
-    if (want(RC_OUT_RAY_DISTS)) {
-      const float ox = a.origins[3 * ray], oy = a.origins[3 * ray + 1], oz = a.origins[3 * ray + 2];
-      const float rd = sqrtf((ox - mx) * (ox - mx) + (oy - my) * (oy - my) + (oz - mz) * (oz - mz));
-      store1(RC_OUT_RAY_DISTS, wave_sum(wc * rd));
-    }
-    if (a.lights && want(RC_OUT_LIGHT_DISTS)) {
-      const float lx = a.lights[3 * ray], ly = a.lights[3 * ray + 1], lz = a.lights[3 * ray + 2];
-      const float ld = sqrtf((lx - mx) * (lx - mx) + (ly - my) * (ly - my) + (lz - mz) * (lz - mz));
-      store1(RC_OUT_LIGHT_DISTS, wave_sum(wc * ld));
-    }
+    if (want(RC_OUT_RAY_DISTS)) store1(RC_OUT_RAY_DISTS, wave_sum(wc * ray_dist()));
+    if (a.lights && want(RC_OUT_LIGHT_DISTS)) store1(RC_OUT_LIGHT_DISTS, wave_sum(wc * light_dist()));
     if (a.normals_pred && want(RC_OUT_NORMALS_PRED)) {
       const float nx = act ? a.normals_pred[pidx] : 0.0f, ny = act ? a.normals_pred[np + pidx] : 0.0f,
                   nz = act ? a.normals_pred[2 * np + pidx] : 0.0f;
@@ -269,6 +288,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
       store3(RC_OUT_NORMALS, wave_sum(wc * nx), wave_sum(wc * ny), wave_sum(wc * nz));
     }
   }
+  store1(RC_OUT_ACC, acc);
 
   // distances (render.py:227-245) always use weights_no_filter
   if (want(RC_OUT_DISTANCE_MEAN) || want(RC_OUT_DISTANCE_PERCENTILE_5) || want(RC_OUT_DISTANCE_MEDIAN) ||

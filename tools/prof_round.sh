@@ -1,20 +1,38 @@
 #!/bin/bash
-# Profiling session of a round (run on the GPU box through gpurun): kernel trace of the default bench
-# (fused plan), of the staged plan, PMC passes (each in its own run), everything under gpurun_out/prof_$1.
+# Profiling session of a round (run on the GPU box through gpurun, from the repo root): kernel traces of the default
+# bench (fused plan), of the staged plan and of the material stage, PMC passes (each in its own run, kernel-trace only),
+# the in-kernel phase stamps of the fused kernel (needs `make -C neural-radiance-caching_amd/csrc diag` beforehand).
+# Everything lands under gpurun_out/prof_$1; copy what is to be kept into profiles/.
 set -e
 R=${1:-r02}
-O=gpurun_out/prof_$R
+ROOT=$PWD
+O=$ROOT/gpurun_out/prof_$R
 mkdir -p $O
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/fused -o fused -- python bench.py --no-cpu-baseline --no-material --no-train --no-image > $O/bench_fused.json 2> $O/fused.err
+B="python $ROOT/bench.py --no-cpu-baseline --no-material --no-train --no-image"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/fused -o fused -- $B > $O/bench_fused.json 2> $O/fused.err
 echo "fused trace done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/staged -o staged -- python bench.py --no-cpu-baseline --no-transient --no-material --no-train --no-image --plan staged > $O/bench_staged.json 2> $O/staged.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/staged -o staged -- $B --no-transient --plan staged > $O/bench_staged.json 2> $O/staged.err
 echo "staged trace done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o fetch -- python bench.py --no-cpu-baseline --no-transient --no-material --no-train --no-image --steps 20 --warmup 5 > /dev/null 2> $O/pmc_fetch.err
-echo "fetch done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o write -- python bench.py --no-cpu-baseline --no-transient --no-material --no-train --no-image --steps 20 --warmup 5 > /dev/null 2> $O/pmc_write.err
-echo "write done"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o mfma -- python bench.py --no-cpu-baseline --no-transient --no-material --no-train --no-image --steps 20 --warmup 5 > /dev/null 2> $O/pmc_mfma.err
-echo "mfma done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/material -o material -- python $ROOT/tools/bench_material.py > $O/bench_material.txt 2> $O/material.err
+echo "material trace done"
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"; do
+  tag=pmc_$(echo $set | cut -d' ' -f1 | tr 'A-Z' 'a-z')
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/$tag -o p -- $B --no-transient --steps 20 --warmup 5 > /dev/null 2> $O/$tag.err
+  echo "$tag done"
+done
+# L1 / L2 / fabric counters of the material stage's kernels (the level kernels above all)
+for set in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
+  tag=mat_$(echo $set | cut -d' ' -f1 | tr 'A-Z' 'a-z')
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/$tag -o p -- python $ROOT/tools/bench_material.py > /dev/null 2> $O/$tag.err
+  echo "$tag done"
+done
+cd $ROOT
 python tools/prof_to_json.py $O $O/pmc_k_cache_fused.json
+python tools/pmc_table.py $O "mat_*" > $O/material_pmc_counters.txt
+if [ -f tools/diag/librc_hip.so ]; then
+  python tools/gpu_stamps_fused.py 1024 "" $O/fused_phase_stamps.json > $O/fused_phase_stamps.txt
+  echo "stamps done"
+fi
 find $O -name "*.csv" | sort
