@@ -807,11 +807,6 @@ __global__ void k_env_combine(int64_t n, const float* rgb_noenv, const float* ac
   }
 }
 
-__global__ void k_make_src(const int32_t* inds, int32_t* src, int64_t n, int S) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n) src[r] = (int32_t)(r * S + inds[r]);
-}
-
 }  // namespace
 
 extern "C" {
@@ -1229,9 +1224,8 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     ra.n_rays = n; ra.S = S2; ra.tdist = W(h, "tdist" + LL); ra.density = W(h, "density" + LL);
     ra.directions = rays->directions; ra.gumbel = rnd->gumbel; ra.inds_in = rnd->resample_inds;
     ra.inds_out = (int32_t*)W(h, "inds"); ra.filt_weight = W(h, "filt_weight"); ra.weights = W(h, "weights" + LL);
+    ra.src_out = (int32_t*)W(h, "src_idx");
     rc_launch_resample(ra, st);
-    hipLaunchKernelGGL(k_make_src, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const int32_t*)W(h, "inds"),
-                       (int32_t*)W(h, "src_idx"), n, S2);
     src = (const int32_t*)W(h, "src_idx");
   }
   const int64_t nsh = resample ? n : np2;
@@ -1547,13 +1541,10 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     ra.n_rays = n; ra.S = S2; ra.tdist = W(h, "tdist" + LL); ra.density = W(h, "density" + LL);
     ra.directions = rays->directions; ra.gumbel = mr->gumbel; ra.inds_in = mr->resample_inds;
     ra.inds_out = (int32_t*)W(h, "inds"); ra.filt_weight = W(h, "filt_weight"); ra.weights = W(h, "weights" + LL);
+    ra.src_out = (int32_t*)W(h, "src_idx");
+    // position and predicted normal of the picked sample = the shading point
+    ra.means = W(h, "means" + LL); ra.normals = W(h, "normals_pred"); ra.pts_out = W(h, "m_pts"); ra.nrm_out = W(h, "m_nrm");
     rc_launch_resample(ra, st);
-    hipLaunchKernelGGL(k_make_src, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const int32_t*)W(h, "inds"),
-                       (int32_t*)W(h, "src_idx"), n, S2);
-    RcMatPointsArgs pa{};
-    pa.n = n; pa.n_src = np2; pa.src = (const int32_t*)W(h, "src_idx"); pa.means = W(h, "means" + LL);
-    pa.normals = W(h, "normals_pred"); pa.pts = W(h, "m_pts"); pa.nrm = W(h, "m_nrm");
-    rc_launch_gather_points(pa, st);
   }
   auto raw = [&](const char* path, const char* leaf) { return h->packs[std::string("raw:") + path + "/" + leaf].p; };
   // Side stream: the material-only composite over all samples (step 3b) and the EnvMap along the secondary rays (step 6b)

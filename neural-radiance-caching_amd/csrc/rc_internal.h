@@ -112,6 +112,12 @@ struct RcResampleArgs {
   int32_t* inds_out;          // [n]
   float* filt_weight;         // [n]
   float* weights;             // [n*S] out (weights_no_filter)
+  int32_t* src_out;           // [n] or nullptr: flat index ray * S + pick of the picked sample (per-pick lookups read through it)
+  // material stage: position and predicted normal of the picked sample, gathered here (all four or none)
+  const float* means;         // SoA [3][n*S]
+  const float* normals;       // SoA [3][n*S]
+  float* pts_out;             // [n,3]
+  float* nrm_out;             // [n,3]
 };
 void rc_launch_resample(const RcResampleArgs& a, hipStream_t stream);
 
@@ -191,12 +197,6 @@ struct RcIdeTable {
 enum { RC_MAT_CH = 5 };   // per point: albedo rgb, roughness, metalness
 enum { RC_VMF_CH = 5 };   // per lobe: normalised mean xyz, kappa, softmax weight
 enum { RC_SMP_CH = 5 };   // per secondary sample: local light dir xyz, pdf, MIS weight
-
-struct RcMatPointsArgs {
-  int64_t n, n_src; const int32_t* src; const float* means; const float* normals;   // SoA [3][n_src]
-  float* pts; float* nrm;                                                            // AoS [n,3]
-};
-void rc_launch_gather_points(const RcMatPointsArgs& a, hipStream_t st);
 
 struct RcMatHeadArgs {
   int64_t n; const float* feat;        // row-major [n,32] material-grid features

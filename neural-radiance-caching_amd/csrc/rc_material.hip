@@ -77,19 +77,6 @@ __device__ __forceinline__ float ggx_d(float c, float a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Gather the filtered shading point of every ray
-// ---------------------------------------------------------------------------------------------
-__global__ void k_gather_points(RcMatPointsArgs a) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= a.n) return;
-  const int64_t q = a.src[r];
-  const float px = a.means[q], py = a.means[a.n_src + q], pz = a.means[2 * a.n_src + q];
-  const float nx = a.normals[q], ny = a.normals[a.n_src + q], nz = a.normals[2 * a.n_src + q];
-  a.pts[3 * r] = px; a.pts[3 * r + 1] = py; a.pts[3 * r + 2] = pz;
-  a.nrm[3 * r] = nx; a.nrm[3 * r + 1] = ny; a.nrm[3 * r + 2] = nz;
-}
-
-// ---------------------------------------------------------------------------------------------
 // Material head: grid features (32) -> Dense 128 -> Dense 10 -> microfacet parameters
 // ---------------------------------------------------------------------------------------------
 // One workgroup takes MH_PTS points: thread t keeps column t of the first layer in registers, so the 16 KB of w0 is
@@ -496,10 +483,6 @@ __global__ __launch_bounds__(256) void k_material_integrate(RcMatIntegrateArgs a
 
 }  // namespace
 
-void rc_launch_gather_points(const RcMatPointsArgs& a, hipStream_t st) {
-  if (a.n <= 0) return;
-  hipLaunchKernelGGL(k_gather_points, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, st, a);
-}
 void rc_launch_material_head(const RcMatHeadArgs& a, hipStream_t st) {
   if (a.n <= 0) return;
   hipLaunchKernelGGL(k_material_head, dim3((unsigned)((a.n + MH_PTS - 1) / MH_PTS)), dim3(128), 0, st, a);

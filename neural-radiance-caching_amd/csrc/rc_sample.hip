@@ -158,6 +158,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_resample(RcResampleArgs
   if (lane == 0) {
     a.inds_out[ray] = ind;
     a.filt_weight[ray] = wsel / (1.0f * psel + 1e-8f);     // models.py:287-289, num_resample = 1
+    if (a.src_out) a.src_out[ray] = (int32_t)(ray * S + ind);
+  }
+  if (a.pts_out && lane < 6) {
+    // lanes 0-2: position, lanes 3-5: predicted normal of the picked sample
+    const int64_t np = a.n_rays * S, q = ray * S + ind;
+    const int c = lane < 3 ? lane : lane - 3;
+    const float v = (lane < 3 ? a.means : a.normals)[c * np + q];
+    (lane < 3 ? a.pts_out : a.nrm_out)[3 * ray + c] = v;
   }
 }
 
