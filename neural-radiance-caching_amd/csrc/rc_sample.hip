@@ -223,7 +223,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
   auto want = [&](int id) { return a.out.ptr[id] != nullptr; };
   const float bgw = fmaxf(0.0f, 1.0f - acc) * a.bg;
   const float wc = contrib ? w : 0.0f;
-  const float mx = act ? a.means[pidx] : 0.0f, my = act ? a.means[np + pidx] : 0.0f, mz = act ? a.means[2 * np + pidx] : 0.0f;
+  const bool components = want(RC_OUT_DIRECT_RGB) || want(RC_OUT_INDIRECT_DIFFUSE_RGB) || want(RC_OUT_INDIRECT_SPECULAR_RGB) ||
+                          want(RC_OUT_SPECULAR_RGB) || want(RC_OUT_ALBEDO_RGB) || want(RC_OUT_DIFFUSE_RGB) || want(RC_OUT_INDIRECT_RGB);
+  const bool pos = act && (components || want(RC_OUT_MEANS) || want(RC_OUT_RAY_DISTS) || want(RC_OUT_LIGHT_DISTS));
+  const float mx = pos ? a.means[pidx] : 0.0f, my = pos ? a.means[np + pidx] : 0.0f, mz = pos ? a.means[2 * np + pidx] : 0.0f;
   auto ray_dist = [&]() {
     const float ox = a.origins[3 * ray], oy = a.origins[3 * ray + 1], oz = a.origins[3 * ray + 2];
     return sqrtf((ox - mx) * (ox - mx) + (oy - my) * (oy - my) + (oz - mz) * (oz - mz));
@@ -232,8 +235,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
     const float lx = a.lights[3 * ray], ly = a.lights[3 * ray + 1], lz = a.lights[3 * ray + 2];
     return sqrtf((lx - mx) * (lx - mx) + (ly - my) * (ly - my) + (lz - mz) * (lz - mz));
   };
-  const bool components = want(RC_OUT_DIRECT_RGB) || want(RC_OUT_INDIRECT_DIFFUSE_RGB) || want(RC_OUT_INDIRECT_SPECULAR_RGB) ||
-                          want(RC_OUT_SPECULAR_RGB) || want(RC_OUT_ALBEDO_RGB) || want(RC_OUT_DIFFUSE_RGB) || want(RC_OUT_INDIRECT_RGB);
   if (components) {
     enum { V_RGB = 0, V_AD = 3, V_IDF = 6, V_IS = 9, V_TINT = 12, V_DIF = 15, V_IND = 18, V_OCC = 21, V_MEAN = 22, V_RD = 25,
            V_LD = 26, V_NP = 27, V_NG = 30, V_COUNT = 33 };
@@ -275,9 +276,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
     if (a.normals_pred) store3(RC_OUT_NORMALS_PRED, v[V_NP], v[V_NP + 1], v[V_NP + 2]);
     if (a.normals_grad) store3(RC_OUT_NORMALS, v[V_NG], v[V_NG + 1], v[V_NG + 2]);
   } else {
-    if (want(RC_OUT_RGB))
-      store3(RC_OUT_RGB, wave_sum(w * shade(RC_SH_RGB)) + bgw, wave_sum(w * shade(RC_SH_RGB + 1)) + bgw,
-             wave_sum(w * shade(RC_SH_RGB + 2)) + bgw);
+    if (want(RC_OUT_RGB)) {
+      float c3[3] = {w * shade(RC_SH_RGB), w * shade(RC_SH_RGB + 1), w * shade(RC_SH_RGB + 2)};    // three loads in flight
+      wave_sum_n<3>(c3);
+      store3(RC_OUT_RGB, c3[0] + bgw, c3[1] + bgw, c3[2] + bgw);
+    }
     if (want(RC_OUT_INDIRECT_OCC)) {
       const float wsum = wave_sum(wc);
       store3(RC_OUT_INDIRECT_OCC, wsum, wsum, wsum);
