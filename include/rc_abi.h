@@ -235,7 +235,10 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n_rays, const rc_r
  * BRDF importance sampling of K secondary rays per point, ONE batched secondary trace of n*K rays through
  * the same cache kernels (is_secondary, resample, no env map) + the model-level EnvMap along the same
  * rays, Monte-Carlo BRDF integration and the MaterialIntegrator composite (-> mat_out).
- * rnd->jitter[] drives the primary rays (NULL: deterministic branch). */
+ * rnd->jitter[] drives the primary rays (NULL: deterministic branch).
+ * Stream semantics: the call is ordered on `stream` like every other entry point.  Inside it, work the secondary
+ * trace does not wait for (light sampler, material-only composite, EnvMap) runs on a stream the handle owns, forked
+ * from and joined back to `stream` with events before the call's last kernel: nothing for the caller to synchronise. */
 int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n_rays, const rc_randoms* rnd,
                        const rc_material_randoms* mrnd, int32_t num_secondary_samples,
                        const rc_outputs* cache_out, const rc_mat_outputs* mat_out, void* stream);

@@ -20,6 +20,14 @@
 // A producer / consumer split of the workgroup (one gather wave per grid level feeding four MLP waves through a
 // double-buffered B-operand ring) was built as well, bitwise equal, and measured slower (343 / 467 / 405 us): it repeats
 // the contraction per level and gains nothing from running the two halves side by side.
+// Counters of the three launches on that trace (profiles/r02_material_pmc_counters.txt): the F = 4 level misses the L2 on
+// 78 % of its 28 M requests -- 21.8 M 64-byte fabric reads = 1.4 GB in 390 us = 3.6 TB/s of random sectors, about one
+// per hashed (y, z) corner pair, which is what the lookup needs -- and its texture-address unit is stalled by the cache
+// for 73 % of the launch: that level runs at the memory side's random-sector rate.  The F = 1 levels read 7.8 / 14.4 M
+// sectors (TA stalled 23 / 33 %) next to 132 us of MFMA time and the gather arithmetic: a mix of the three.
+// Copies of the hashed F = 1 tables with the two x-corners of a cell adjacent (one 8-byte load for 15 of 16 lanes with
+// four copies) were built, bitwise equal, and measured slower (+26 / +100 us): they multiply the footprint the L2 sees,
+// and the number of L1 lookups was not the bound.
 #include "rc_dev_grid.h"
 #include "rc_dev_mlp.h"
 #include "rc_dev_sample.h"
