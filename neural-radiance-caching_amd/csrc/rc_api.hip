@@ -1165,18 +1165,24 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     sa.use_raydist = (secondary || h->transient) ? 1 : 0;     // TransientNeRFModel: use_raydist_for_secondary_only = False
     sa.raydist_p = c.raydist_p; sa.raydist_premult = c.raydist_premult;
     sa.eps_dot_min = c.shadow_normal_eps_dot_min; sa.far_clamp = c.env_map_distance;
+    const bool want_grad = (l == NL - 1) && (A.out.ptr[RC_OUT_NORMALS] != nullptr || A.force_grad);
+    // only the density of this level's samples is consumed behind it (proposal levels; the last level on the lean
+    // resampling pass): grid lookup + density MLP as ONE launch, weights resident in LDS (rc_level.hip) -- and on the
+    // default plan (rc_set_fused 1) the level's sampling in front of it in the same launch, one ray per wave
+    const bool level_kernel = h->fused_mode != 0 && !h->profiling && rc_level_supported(h->grids[l].dev) && !want_grad &&
+                              (l < NL - 1 || (lean && !A.tout));
+    RcLevelArgs la{};
+    la.grid = &h->grids[l].dev; la.means = W(h, "means" + L); la.n = np; la.wstream = h->packs["dens_" + L].p;
+    la.density_bias = c.density_bias; la.contract_radius = c.contract_radius; la.density = W(h, "density" + L);
+    if (level_kernel && h->fused_mode == 1 && rc_level_ray_supported(h->grids[l].dev, S)) {
+      rc_launch_level_ray(la, sa, st);
+      continue;
+    }
     stage_mark(h, slot, ST_SAMPLE0 + 3 * l, st);
     rc_launch_sample(sa, st);
 
     stage_mark(h, slot, ST_GRID0 + 3 * l, st);
-    const bool want_grad = (l == NL - 1) && (A.out.ptr[RC_OUT_NORMALS] != nullptr || A.force_grad);
-    // only the density of this level's samples is consumed behind it (proposal levels; the last level on the lean
-    // resampling pass): grid lookup + density MLP as ONE launch, weights resident in LDS (rc_level.hip)
-    if (h->fused_mode != 0 && !h->profiling && rc_level_supported(h->grids[l].dev) && !want_grad &&
-        (l < NL - 1 || (lean && !A.tout))) {
-      RcLevelArgs la{};
-      la.grid = &h->grids[l].dev; la.means = W(h, "means" + L); la.n = np; la.wstream = h->packs["dens_" + L].p;
-      la.density_bias = c.density_bias; la.contract_radius = c.contract_radius; la.density = W(h, "density" + L);
+    if (level_kernel) {
       stage_mark(h, slot, ST_MLP0 + 3 * l, st);
       rc_launch_level(la, st);
       continue;

@@ -190,6 +190,92 @@ __device__ __forceinline__ void sample_intervals_wave(float logit, int P, int S,
   lds_sync<BLOCK_SYNC>();
 }
 
+// One level of the proposal sampler for one ray on one wave (the body of k_sample_level; also the first half of
+// rc_level.hip's per-ray level kernel): weights of the previous level -> resampling logits -> sample_intervals ->
+// s -> t -> cast.  `lds`: this wave's 5 x (kSlots + 3) floats.  Stores sdist / tdist / means (and the previous level's
+// weights) when ray_ok; returns the sample mean of interval `lane` (lanes < S).
+// Replaces sampling.py:284-639 per level, coord.py:223-260, render.py:49-59, 106-131, sampling.py:182-205.
+__device__ __forceinline__ void sample_level_ray(const RcSampleArgs& a, const USpec& us, float y_max, int64_t ray, bool ray_ok,
+                                                 float* lds, int lane, float& mean_x, float& mean_y, float& mean_z) {
+  float* s_t = lds;
+  float* s_cw = lds + (kSlots + 3);
+  float* s_c = lds + 2 * (kSlots + 3);
+  float* s_v = lds + 3 * (kSlots + 3);
+  float* s_out = lds + 4 * (kSlots + 3);
+
+  const float ox = a.origins[3 * ray], oy = a.origins[3 * ray + 1], oz = a.origins[3 * ray + 2];
+  const float dx = a.directions[3 * ray], dy = a.directions[3 * ray + 1], dz = a.directions[3 * ray + 2];
+  float near = a.near[ray], far = a.far[ray];
+  if (a.secondary) {
+    far = fminf(far, a.far_clamp);                                  // models.py:670-673
+    if (a.normals) {                                                // sampling.py:182-205
+      const float dp = a.viewdirs[3 * ray] * a.normals[3 * ray] + a.viewdirs[3 * ray + 1] * a.normals[3 * ray + 1] +
+                       a.viewdirs[3 * ray + 2] * a.normals[3 * ray + 2];
+      float off = fminf(fmaxf(a.eps_dot_min / fmaxf(dp, 1e-5f), near), far);
+      off = dp > 0.0f ? off : near;
+      near = fmaxf(near, off);
+      near = fminf(fmaxf(near, 1e-5f), far - 1e-5f);
+    }
+  }
+  const int P = a.P, S = a.S;
+
+  // --- weights of the previous level -> resampling logits (sampling.py:339)
+  float w;
+  if (a.prev_sdist == nullptr) {
+    w = 1.0f;
+    if (lane == 0) { s_t[0] = 0.0f; s_t[1] = 1.0f; }
+  } else {
+    const bool act = lane < P;
+    const float t0 = act ? a.prev_tdist[ray * (P + 1) + lane] : 0.0f;
+    const float t1 = act ? a.prev_tdist[ray * (P + 1) + lane + 1] : 0.0f;
+    const float dens = act ? a.prev_density[ray * P + lane] : 0.0f;
+    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+    w = alpha_weight(dens, t0, t1, dnorm, act, lane);
+    if (act && ray_ok && a.prev_weights) a.prev_weights[ray * P + lane] = w;
+    for (int e2 = lane; e2 <= P; e2 += 64) s_t[e2] = a.prev_sdist[ray * (P + 1) + e2];
+  }
+  const float logit = a.anneal * safe_log(w + a.padding);
+  const bool hasj = a.jitter != nullptr;
+  const float jit = hasj ? a.jitter[ray] : 0.0f;
+  // every wave works on its own LDS slice: wave-local hand-offs, and the exact rank sort of jnp.sort only when the
+  // clipped fence posts really contain an inversion (same values as the unconditional sort)
+  lds_sync<false>();
+  sample_intervals_wave<false>(logit, P, S, us, hasj, jit, s_t, s_cw, s_c, s_v, s_out, lane);
+
+  // --- s -> t (coord.py:259-260), cast (render.py:49-59, 106-131)
+  float s_near = 0.0f, s_far = 0.0f;
+  if (a.use_raydist) {
+    s_near = power_ladder(near, a.raydist_p, a.raydist_premult);
+    s_far = power_ladder(far, a.raydist_p, a.raydist_premult);
+  }
+  for (int e2 = lane; e2 <= S; e2 += 64) {
+    const float s = s_out[e2];
+    float t;
+    if (a.use_raydist) t = inv_power_ladder(s * s_far + (1.0f - s) * s_near, a.raydist_p, a.raydist_premult, y_max);
+    else t = s * far + (1.0f - s) * near;
+    s_v[e2] = t;
+    if (ray_ok) {
+      a.sdist[ray * (S + 1) + e2] = s;
+      a.tdist[ray * (S + 1) + e2] = t;
+    }
+  }
+  lds_sync<false>();
+  mean_x = 0.0f; mean_y = 0.0f; mean_z = 0.0f;
+  if (lane < S) {
+    const float t0 = s_v[lane], t1 = s_v[lane + 1];
+    const float sm = t0 + t1, d = t1 - t0;
+    const float ratio = (d * d) / fmaxf(RC_EPS * RC_EPS, 3.0f * (sm * sm) + d * d);
+    const float tm = sm * (0.5f + ratio);
+    mean_x = dx * tm + ox; mean_y = dy * tm + oy; mean_z = dz * tm + oz;
+    if (ray_ok && a.means) {
+      const int64_t np = a.n_rays * S, pidx = ray * S + lane;
+      a.means[pidx] = mean_x;
+      a.means[np + pidx] = mean_y;
+      a.means[2 * np + pidx] = mean_z;
+    }
+  }
+}
+
 // jnp.interp(x, xp, fp) on LDS arrays of length m (stepfun.weighted_percentile).
 __device__ __forceinline__ float interp1(float x, const float* xp, const float* fp, int m) {
   int i = upper_bound(xp, m, x);

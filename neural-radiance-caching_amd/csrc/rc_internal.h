@@ -155,6 +155,9 @@ struct RcLevelArgs {
 };
 bool rc_level_supported(const RcGridDev& g);
 void rc_launch_level(const RcLevelArgs& a, hipStream_t stream);
+// the level's sampling (rc_launch_sample) and the level itself as ONE launch, one ray per wave
+bool rc_level_ray_supported(const RcGridDev& g, int S);
+void rc_launch_level_ray(const RcLevelArgs& a, const RcSampleArgs& sa, hipStream_t stream);
 
 struct RcShaderArgs {
   int64_t n;                  // shaded points

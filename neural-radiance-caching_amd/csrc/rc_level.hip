@@ -53,34 +53,31 @@ struct RcLevelKArgs {
 
 // NL grid levels of F features: K = NL * F grid features, KS0 = K / 2 (rounded up) + 1 k-steps in layer 0.
 template <int F, int NL>
-__global__ __launch_bounds__(LevelCfg<F>::W * 64) void k_level(RcLevelKArgs a) {
-  constexpr int W = LevelCfg<F>::W;
-  constexpr int K = F * NL, KS0 = (K + 1) / 2 + 1;
-  constexpr int NOB = KS0 == 17 ? 4 : 1;                                   // rows the output layer was packed with
-  constexpr int F_D0 = 0, F_D1 = 2 * KS0, F_DO = 2 * KS0 + 66, NF = F_DO + NOB * 33;
-  constexpr int CH = 288;     // > NF and a multiple of 4 W (ws_issue is instantiated, never run): the whole stream is one resident chunk
+struct LevelK {
+  static constexpr int W = LevelCfg<F>::W;
+  static constexpr int K = F * NL, KS0 = (K + 1) / 2 + 1;
+  static constexpr int NOB = KS0 == 17 ? 4 : 1;                            // rows the output layer was packed with
+  static constexpr int F_D0 = 0, F_D1 = 2 * KS0, F_DO = 2 * KS0 + 66, NF = F_DO + NOB * 33;
+  static constexpr int CH = 288;   // > NF and a multiple of 4 W (ws_issue is instantiated, never run): the whole stream is one resident chunk
   static_assert(NF <= CH && CH % (4 * W) == 0, "stream must fit the resident chunk");
-  extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-  float* wres = lds_dyn;                                                    // [NF padded to 4][64]
-  constexpr int kResFloats = ((NF + 3) / 4) * 4 * 64;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float* act_wave = lds_dyn + kResFloats + wave * (kLvActSteps * 64);
-  float* act = act_wave + lane;
+  static constexpr int kResFloats = ((NF + 3) / 4) * 4 * 64;               // [NF padded to 4][64]
+
   // the level's weights: once per workgroup, LDS-DMA in 1-KiB pieces (the packed stream is padded to whole 16-KiB chunks)
-  for (int piece = wave; piece < (NF + 3) / 4; piece += W)
-    __builtin_amdgcn_global_load_lds((const void*)(a.wstream + (size_t)piece * 256 + lane * 4), (lds_void_ptr)(wres + piece * 256), 16, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  WStream ws{a.wstream, wres, lane, wave};
-  const int j = lane & 31, h = lane >> 5;
-  const int64_t tiles = (a.n + 31) / 32;
-  const float bbox = a.grid.bbox;
-  for (int64_t tile = (int64_t)blockIdx.x * W + wave; tile < tiles; tile += (int64_t)gridDim.x * W) {
-    const int64_t p = tile * 32 + j;
-    const bool valid = p < a.n;
-    const int64_t q = valid ? p : a.n - 1;
-    float cx = a.means[q], cy = a.means[a.n + q], cz = a.means[2 * a.n + q];
-    contract3(cx, cy, cz, a.contract_radius);
+  static __device__ __forceinline__ void load_weights(const float* wstream, float* wres, int wave, int lane) {
+    for (int piece = wave; piece < (NF + 3) / 4; piece += W)
+      __builtin_amdgcn_global_load_lds((const void*)(wstream + (size_t)piece * 256 + lane * 4), (lds_void_ptr)(wres + piece * 256), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // One 32-point tile on this wave's activation slice: contraction, grid lookup, density MLP, convert_raw_density.
+  // (cx, cy, cz): the position of point j = lane & 31, the same on both half-waves.  Returns the density (all lanes).
+  static __device__ __forceinline__ float tile(const RcGridDev& grid, float density_bias, float contract_radius, const WStream& ws,
+                                               float* act_wave, int lane, float cx, float cy, float cz) {
+    const int j = lane & 31, h = lane >> 5;
+    float* act = act_wave + lane;
+    const float bbox = grid.bbox;
+    contract3(cx, cy, cz, contract_radius);
     const float ux = unit_box(bbox, cx), uy = unit_box(bbox, cy), uz = unit_box(bbox, cz);
     // this half-wave's levels: l = 2 i + h (all their corner loads in flight before the first combine)
     constexpr int NH = (NL + 1) / 2;
@@ -89,7 +86,7 @@ __global__ __launch_bounds__(LevelCfg<F>::W * 64) void k_level(RcLevelKArgs a) {
     for (int i = 0; i < NH; ++i) {
       const int l = 2 * i + h;
       if (l < NL) {
-        const RcGridLevel& L = a.grid.lvl[l];
+        const RcGridLevel& L = grid.lvl[l];
         if constexpr (F == 1) {
           if (L.cell) grid_fetch<1, false, 1, true>(L.cell, L.size, L.mask, L.entries, true, ux, uy, uz, C[i]);
           else grid_fetch<1>(L.table, L.size, L.mask, L.entries, L.dense != 0, ux, uy, uz, C[i]);
@@ -108,7 +105,7 @@ __global__ __launch_bounds__(LevelCfg<F>::W * 64) void k_level(RcLevelKArgs a) {
         if (i < NH && l < NL) {
           float f[1], jd[1];
           grid_combine<1, false>(C[i < NH ? i : 0], f, jd);
-          v = f[0] * a.grid.precondition;
+          v = f[0] * grid.precondition;
         }
         act[i * 64] = v;
       }
@@ -121,7 +118,7 @@ __global__ __launch_bounds__(LevelCfg<F>::W * 64) void k_level(RcLevelKArgs a) {
           float f[4], jd[1];
           grid_combine<4, false>(C[i], f, jd);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) act_wave[(2 * l + (c >> 1)) * 64 + j + 32 * (c & 1)] = f[c] * a.grid.precondition;
+          for (int c = 0; c < 4; ++c) act_wave[(2 * l + (c >> 1)) * 64 + j + 32 * (c & 1)] = f[c] * grid.precondition;
         }
       }
     }
@@ -136,21 +133,76 @@ __global__ __launch_bounds__(LevelCfg<F>::W * 64) void k_level(RcLevelKArgs a) {
     mlp_layer<2, 33, F_D1, NF, 4, W, CH>(ws, act, acc);
     float out[1], nokeep[1];
     dot_out1<2, 1, F_DO, NF, false, W, NOB, CH>(ws, acc, out, nokeep);     // output_density_layer on relu(acc)
-    if (h == 0 && valid) {
-      // convert_raw_density (geometry.py:318-341)
-      const bool inside = (cx > -bbox) & (cx < bbox) & (cy > -bbox) & (cy < bbox) & (cz > -bbox) & (cz < bbox);
-      const float d = expf(fminf(fmaxf(out[0] + a.density_bias, -RC_FMAX), 70.0f));
-      a.density[p] = inside ? d : 0.0f;
-    }
+    // convert_raw_density (geometry.py:318-341)
+    const bool inside = (cx > -bbox) & (cx < bbox) & (cy > -bbox) & (cy < bbox) & (cz > -bbox) & (cz < bbox);
+    const float d = expf(fminf(fmaxf(out[0] + density_bias, -RC_FMAX), 70.0f));
     lds_sync_wave();        // the next tile's feature writes must not overtake this tile's activation reads
+    return inside ? d : 0.0f;
+  }
+};
+
+template <int F, int NL>
+__global__ __launch_bounds__(LevelCfg<F>::W * 64) void k_level(RcLevelKArgs a) {
+  using LK = LevelK<F, NL>;
+  constexpr int W = LK::W;
+  extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  float* wres = lds_dyn;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* act_wave = lds_dyn + LK::kResFloats + wave * (kLvActSteps * 64);
+  LK::load_weights(a.wstream, wres, wave, lane);
+  WStream ws{a.wstream, wres, lane, wave};
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t tiles = (a.n + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * W + wave; tile < tiles; tile += (int64_t)gridDim.x * W) {
+    const int64_t p = tile * 32 + j;
+    const bool valid = p < a.n;
+    const int64_t q = valid ? p : a.n - 1;
+    const float d = LK::tile(a.grid, a.density_bias, a.contract_radius, ws, act_wave, lane, a.means[q], a.means[a.n + q], a.means[2 * a.n + q]);
+    if (h == 0 && valid) a.density[p] = d;
+  }
+}
+
+// The same per ray, with the level's sampling in front (rc_dev_sample.h sample_level_ray = k_sample_level): a wave takes a
+// ray, draws its S samples, then walks its S / 32 tiles -- the sample means go from registers straight into the lookup,
+// the sampler's scans and searches run in the shadow of the other waves' gathers.  One launch per proposal level.
+struct RcLevelRayKArgs {
+  RcLevelKArgs lv;             // lv.means unused
+  RcSampleArgs sa;
+  USpec us;
+  float y_max;
+};
+
+constexpr int kLvSampFloats = 5 * (kSlots + 3);
+
+template <int F, int NL, int S>
+__global__ __launch_bounds__(LevelCfg<F>::W * 64) void k_level_ray(RcLevelRayKArgs a) {
+  using LK = LevelK<F, NL>;
+  constexpr int W = LK::W;
+  extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  float* wres = lds_dyn;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* act_wave = lds_dyn + LK::kResFloats + wave * (kLvActSteps * 64);
+  float* samp = lds_dyn + LK::kResFloats + W * (kLvActSteps * 64) + wave * kLvSampFloats;
+  LK::load_weights(a.lv.wstream, wres, wave, lane);
+  WStream ws{a.lv.wstream, wres, lane, wave};
+  const int j = lane & 31, h = lane >> 5;
+  for (int64_t ray = (int64_t)blockIdx.x * W + wave; ray < a.sa.n_rays; ray += (int64_t)gridDim.x * W) {
+    float mx, my, mz;
+    sample_level_ray(a.sa, a.us, a.y_max, ray, true, samp, lane, mx, my, mz);
+#pragma unroll
+    for (int t = 0; t < S / 32; ++t) {
+      const float px = __shfl(mx, 32 * t + j, 64), py = __shfl(my, 32 * t + j, 64), pz = __shfl(mz, 32 * t + j, 64);
+      const float d = LK::tile(a.lv.grid, a.lv.density_bias, a.lv.contract_radius, ws, act_wave, lane, px, py, pz);
+      if (h == 0) a.lv.density[ray * S + 32 * t + j] = d;
+    }
   }
 }
 
 template <int F, int NL>
 void launch_level(const RcLevelKArgs& a, hipStream_t stream) {
-  constexpr int W = LevelCfg<F>::W;
-  constexpr int K = F * NL, KS0 = (K + 1) / 2 + 1, NOB = KS0 == 17 ? 4 : 1, NF = 2 * KS0 + 66 + NOB * 33;
-  const int lds = (((NF + 3) / 4) * 4 * 64 + W * kLvActSteps * 64) * (int)sizeof(float);
+  using LK = LevelK<F, NL>;
+  constexpr int W = LK::W;
+  const int lds = (LK::kResFloats + W * kLvActSteps * 64) * (int)sizeof(float);
   static std::atomic<uint64_t> prepared{0};
   if (rc_first_use_on_device(prepared))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_level<F, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -163,11 +215,45 @@ void launch_level(const RcLevelKArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL((k_level<F, NL>), grid, block, lds, stream, a);
 }
 
+template <int F, int NL, int S>
+void launch_level_ray(const RcLevelRayKArgs& a, hipStream_t stream) {
+  using LK = LevelK<F, NL>;
+  constexpr int W = LK::W;
+  const int lds = (LK::kResFloats + W * (kLvActSteps * 64 + kLvSampFloats)) * (int)sizeof(float);
+  static std::atomic<uint64_t> prepared{0};
+  if (rc_first_use_on_device(prepared))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_level_ray<F, NL, S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int64_t want = (a.sa.n_rays + W - 1) / W;
+  dim3 grid((unsigned)(want < cus ? want : cus)), block(W * 64);
+  hipLaunchKernelGGL((k_level_ray<F, NL, S>), grid, block, lds, stream, a);
+}
+
 }  // namespace
 
 // true when (F, number of levels) is one of the compiled shapes
 bool rc_level_supported(const RcGridDev& g) {
   return (g.num_features == 1 && (g.num_levels == 6 || g.num_levels == 7)) || (g.num_features == 4 && g.num_levels == 8);
+}
+
+// sampling + level as one launch: supported shapes of rc_level_supported with 64 (F = 1) or 32 (F = 4) samples per ray
+bool rc_level_ray_supported(const RcGridDev& g, int S) {
+  return rc_level_supported(g) && S == (g.num_features == 1 ? 64 : 32);
+}
+
+void rc_launch_level_ray(const RcLevelArgs& A, const RcSampleArgs& sa, hipStream_t stream) {
+  if (sa.n_rays <= 0) return;
+  RcLevelRayKArgs a{};
+  a.lv.grid = *A.grid; a.lv.means = nullptr; a.lv.n = A.n; a.lv.wstream = A.wstream;
+  a.lv.density_bias = A.density_bias; a.lv.contract_radius = A.contract_radius; a.lv.density = A.density;
+  a.sa = sa;
+  a.us = make_uspec(sa.S, sa.jitter != nullptr);
+  a.y_max = sa.raydist_p < 0.0f ? nextafterf((sa.raydist_p - 1.0f) / sa.raydist_p, -INFINITY) : 0.0f;      // as rc_launch_sample
+  if (a.lv.grid.num_features == 1 && a.lv.grid.num_levels == 6) launch_level_ray<1, 6, 64>(a, stream);
+  else if (a.lv.grid.num_features == 1 && a.lv.grid.num_levels == 7) launch_level_ray<1, 7, 64>(a, stream);
+  else if (a.lv.grid.num_features == 4 && a.lv.grid.num_levels == 8) launch_level_ray<4, 8, 32>(a, stream);
 }
 
 void rc_launch_level(const RcLevelArgs& A, hipStream_t stream) {

@@ -22,80 +22,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_sample_level(RcSampleAr
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   const bool ray_ok = ray < a.n_rays;
-  if (!ray_ok) ray = a.n_rays - 1;   // keep the wave alive for the block barriers; stores are masked
-  float* s_t = lds[wave][0];
-  float* s_cw = lds[wave][1];
-  float* s_c = lds[wave][2];
-  float* s_v = lds[wave][3];
-  float* s_out = lds[wave][4];
-
-  const float ox = a.origins[3 * ray], oy = a.origins[3 * ray + 1], oz = a.origins[3 * ray + 2];
-  const float dx = a.directions[3 * ray], dy = a.directions[3 * ray + 1], dz = a.directions[3 * ray + 2];
-  float near = a.near[ray], far = a.far[ray];
-  if (a.secondary) {
-    far = fminf(far, a.far_clamp);                                  // models.py:670-673
-    if (a.normals) {                                                // sampling.py:182-205
-      const float dp = a.viewdirs[3 * ray] * a.normals[3 * ray] + a.viewdirs[3 * ray + 1] * a.normals[3 * ray + 1] +
-                       a.viewdirs[3 * ray + 2] * a.normals[3 * ray + 2];
-      float off = fminf(fmaxf(a.eps_dot_min / fmaxf(dp, 1e-5f), near), far);
-      off = dp > 0.0f ? off : near;
-      near = fmaxf(near, off);
-      near = fminf(fmaxf(near, 1e-5f), far - 1e-5f);
-    }
-  }
-  const int P = a.P, S = a.S;
-
-  // --- weights of the previous level -> resampling logits (sampling.py:339)
-  float w;
-  if (a.prev_sdist == nullptr) {
-    w = 1.0f;
-    if (lane == 0) { s_t[0] = 0.0f; s_t[1] = 1.0f; }
-  } else {
-    const bool act = lane < P;
-    const float t0 = act ? a.prev_tdist[ray * (P + 1) + lane] : 0.0f;
-    const float t1 = act ? a.prev_tdist[ray * (P + 1) + lane + 1] : 0.0f;
-    const float dens = act ? a.prev_density[ray * P + lane] : 0.0f;
-    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
-    w = alpha_weight(dens, t0, t1, dnorm, act, lane);
-    if (act && ray_ok && a.prev_weights) a.prev_weights[ray * P + lane] = w;
-    for (int e2 = lane; e2 <= P; e2 += 64) s_t[e2] = a.prev_sdist[ray * (P + 1) + e2];
-  }
-  const float logit = a.anneal * safe_log(w + a.padding);
-  const bool hasj = a.jitter != nullptr;
-  const float jit = hasj ? a.jitter[ray] : 0.0f;
-  // every wave works on its own LDS slice: wave-local hand-offs, and the exact rank sort of jnp.sort only when the
-  // clipped fence posts really contain an inversion (same values as the unconditional sort)
-  lds_sync<false>();
-  sample_intervals_wave<false>(logit, P, S, us, hasj, jit, s_t, s_cw, s_c, s_v, s_out, lane);
-
-  // --- s -> t (coord.py:259-260), cast (render.py:49-59, 106-131)
-  float s_near = 0.0f, s_far = 0.0f;
-  if (a.use_raydist) {
-    s_near = power_ladder(near, a.raydist_p, a.raydist_premult);
-    s_far = power_ladder(far, a.raydist_p, a.raydist_premult);
-  }
-  for (int e2 = lane; e2 <= S; e2 += 64) {
-    const float s = s_out[e2];
-    float t;
-    if (a.use_raydist) t = inv_power_ladder(s * s_far + (1.0f - s) * s_near, a.raydist_p, a.raydist_premult, y_max);
-    else t = s * far + (1.0f - s) * near;
-    s_v[e2] = t;
-    if (ray_ok) {
-      a.sdist[ray * (S + 1) + e2] = s;
-      a.tdist[ray * (S + 1) + e2] = t;
-    }
-  }
-  lds_sync<false>();
-  if (lane < S && ray_ok) {
-    const float t0 = s_v[lane], t1 = s_v[lane + 1];
-    const float sm = t0 + t1, d = t1 - t0;
-    const float ratio = (d * d) / fmaxf(RC_EPS * RC_EPS, 3.0f * (sm * sm) + d * d);
-    const float tm = sm * (0.5f + ratio);
-    const int64_t np = a.n_rays * S, pidx = ray * S + lane;
-    a.means[pidx] = dx * tm + ox;
-    a.means[np + pidx] = dy * tm + oy;
-    a.means[2 * np + pidx] = dz * tm + oz;
-  }
+  if (!ray_ok) ray = a.n_rays - 1;   // keep the wave alive; stores are masked
+  float mx, my, mz;
+  sample_level_ray(a, us, y_max, ray, ray_ok, &lds[wave][0][0], lane, mx, my, mz);
 }
 
 __global__ __launch_bounds__(kWavesPerBlock * 64) void k_sample_intervals(const float* __restrict__ t,
