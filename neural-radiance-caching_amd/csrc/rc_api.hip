@@ -1174,7 +1174,8 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     RcLevelArgs la{};
     la.grid = &h->grids[l].dev; la.means = W(h, "means" + L); la.n = np; la.wstream = h->packs["dens_" + L].p;
     la.density_bias = c.density_bias; la.contract_radius = c.contract_radius; la.density = W(h, "density" + L);
-    if (level_kernel && h->fused_mode == 1 && rc_level_ray_supported(h->grids[l].dev, S)) {
+    // (one ray per wave pays from ~100 rays per CU on: measured break-even of the whole pass near 32 k rays, +27 us at 1-4 k)
+    if (level_kernel && h->fused_mode == 1 && n >= 24576 && rc_level_ray_supported(h->grids[l].dev, S)) {
       rc_launch_level_ray(la, sa, st);
       continue;
     }

@@ -178,12 +178,13 @@ def test_level_kernels_equal_the_separate_gather_and_mlp_kernels(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [3, 130])
+@pytest.mark.parametrize("n", [3, 130, 768])
 def test_material_stage_is_bitwise_the_same_on_every_launch_plan(n):
     """rc_render_material on the three launch plans of rc_set_fused: 1 (default) runs the primary cache pass as the ONE
     fused launch with its per-sample results exported for the shading-point pick, 2 the launch-per-stage pass with the
     level kernels, 0 one kernel per stage.  Every cache and material output, the picks and the secondary radiance are
-    bitwise equal."""
+    bitwise equal.  (768 primary rays = 24 576 secondary rays: from there on plan 1 runs a proposal level of the trace
+    with its sampling in front as ONE launch, one ray per wave -- k_level_ray.)"""
     from oracle import material_ref
     from nrc_amd import rc_ext
     cfg = nrc_amd.hotdog_config()
@@ -205,3 +206,33 @@ def test_material_stage_is_bitwise_the_same_on_every_launch_plan(n):
     for mode in (2, 1):
         for k in res[0]:
             assert torch.equal(res[0][k].cpu(), res[mode][k].cpu()), (mode, k)
+
+
+def test_level_kernel_with_its_sampling_in_front_equals_the_separate_kernels():
+    """rc_set_fused(1) on a batch of >= 24 576 rays: k_level_ray (sample_level_ray + the level's lookup and MLP, one ray per
+    wave) against k_sample_level + k_level (plan 2) and the one-kernel-per-stage plan (0), on a ragged ray count, for the
+    resampling pass of primary rays and for secondary rays: fence posts, densities and outputs bitwise equal."""
+    from nrc_amd import rc_ext
+    rc = common.make_rc()
+    rc.set_graph_mode(0)
+    n = 25001
+    rays = nrc_amd.synthetic_rays(n, seed=41).hot_fields()
+    jit = common.jitters(n, seed=6)
+    srays, srnd = common.secondary_case(n, seed=13)
+    g = np.random.default_rng(5).gumbel(size=(n, 32)).astype(np.float32)
+    cases = [(rays, {"jitter": jit, "gumbel": g}, rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_RESAMPLE, ["rgb", "acc", "means"]),
+             (srays, srnd, rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_SECONDARY | rc_ext.RC_PASS_NO_ENVMAP, ["rgb", "acc"])]
+    for fields, rnd, mask, outs in cases:
+        res = {}
+        for mode in (0, 2, 1):
+            rc.set_fused(mode)
+            o = rc.render_rays(fields, rnd, mask, outputs=outs)
+            torch.cuda.synchronize()
+            res[mode] = {k: v.clone() for k, v in o.items()}
+            for nm, cnt in (("density0", n * 64), ("density1", n * 64), ("density2", n * 32), ("tdist0", n * 65),
+                            ("sdist1", n * 65), ("tdist2", n * 33), ("means1", 3 * n * 64)):
+                res[mode][nm] = torch.from_numpy(rc.workspace(nm)[:cnt].copy())
+        for mode in (2, 1):
+            for k in res[0]:
+                assert torch.equal(res[0][k].cpu(), res[mode][k].cpu()), (mask, mode, k)
+    rc.set_fused(1)
