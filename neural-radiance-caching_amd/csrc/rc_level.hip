@@ -7,6 +7,12 @@
 //   coord.contract, HashEncoding.__call__                           internal/coord.py:37-69, internal/grid_utils.py:808-905
 //   DensityMLP.run_network, convert_raw_density                      internal/geometry.py:155-168, 318-341
 //
+// Two forms: k_level walks 32-sample tiles of a level whose sample means k_sample_level left in the workspace;
+// k_level_ray takes a ray per wave, draws the level's samples itself (rc_dev_sample.h sample_level_ray, the body of
+// k_sample_level) and walks the ray's tiles -- one launch per proposal level instead of two, the means never leave the
+// registers on their way into the lookup (rc_api.hip picks it from 24 576 rays on: (55 + 290) -> 316, (55 + 330) -> 350,
+// (50 + 390) -> 411 us on the trace below; at 1-4 k rays the per-ray form costs 27 us per pass).
+//
 // Why: on the material stage's batched secondary trace (32 768 rays, 2 M + 2 M + 1 M samples) the two kernels per level
 // ran back to back -- with the grid features going through HBM in between, and the MLP at 36-54 % of the MFMA rate
 // because every 128-point workgroup re-streamed the level's weights and paid a start-up.  Here the level's whole weight
