@@ -1072,6 +1072,7 @@ struct RenderArgs {
   const rc_transient_outputs* tout = nullptr; const float* cam_origins = nullptr;
   const rc_randoms* shadow_rnd = nullptr; bool weights_only = false; bool force_grad = false;
   bool export_samples = false;     // fused plan: leave tdist / density / means / normals_pred of the last level in the workspace
+  const float* s_bounds = nullptr; // secondary rays with ONE (near, far): power-ladder bounds computed once (RcSampleArgs)
 };
 
 void enqueue_transient_tail(rc_handle* h, const RenderArgs& A, hipStream_t st);
@@ -1165,6 +1166,7 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     sa.use_raydist = (secondary || h->transient) ? 1 : 0;     // TransientNeRFModel: use_raydist_for_secondary_only = False
     sa.raydist_p = c.raydist_p; sa.raydist_premult = c.raydist_premult;
     sa.eps_dot_min = c.shadow_normal_eps_dot_min; sa.far_clamp = c.env_map_distance;
+    sa.s_bounds = (secondary && !rays->normals) ? A.s_bounds : nullptr;
     const bool want_grad = (l == NL - 1) && (A.out.ptr[RC_OUT_NORMALS] != nullptr || A.force_grad);
     // only the density of this level's samples is consumed behind it (proposal levels; the last level on the lean
     // resampling pass): grid lookup + density MLP as ONE launch, weights resident in LDS (rc_level.hip) -- and on the
@@ -1523,7 +1525,7 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
       (rc = ws_alloc(h, "sec_dirs", 3 * nsec)) || (rc = ws_alloc(h, "sec_near", nsec)) || (rc = ws_alloc(h, "sec_far", nsec)) ||
       (rc = ws_alloc(h, "sec_lights", 3 * nsec)) || (rc = ws_alloc(h, "sec_samples", RC_SMP_CH * nsec)) ||
       (rc = ws_alloc(h, "m_local_view", 3 * n)) || (rc = ws_alloc(h, "sec_rgb", 3 * nsec)) ||
-      (rc = ws_alloc(h, "sec_acc", nsec)) || (rc = ws_alloc(h, "sec_env", 3 * nsec)))
+      (rc = ws_alloc(h, "sec_acc", nsec)) || (rc = ws_alloc(h, "sec_env", 3 * nsec)) || (rc = ws_alloc(h, "sec_sbounds", 2)))
     return rc;
   h->ws_prefix = "s:";
   rc = ensure_workspace(h, nsec);
@@ -1617,6 +1619,11 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     for (int l = 0; l < RC_MAX_LEVELS; ++l) B.rnd.jitter[l] = mr->sec_jitter[l];
     B.rnd.gumbel = mr->sec_gumbel; B.rnd.resample_inds = mr->sec_resample_inds;
     B.n = nsec; B.mask = RC_PASS_CACHE | RC_PASS_SECONDARY | RC_PASS_NO_ENVMAP; B.slot = -1;
+    // every secondary ray of this trace has the same (near, far) (k_brdf_sample writes the two constants): the
+    // power-ladder image of the pair is computed once instead of by each of the 3 x 32 768 sampler waves
+    rc_launch_ladder_bounds(c.secondary_near, c.secondary_far, c.env_map_distance, c.raydist_p, c.raydist_premult,
+                            W(h, "sec_sbounds"), st);
+    B.s_bounds = W(h, "sec_sbounds");
     memset(&B.out, 0, sizeof(B.out));
     B.out.ptr[RC_OUT_RGB] = W(h, "sec_rgb"); B.out.ptr[RC_OUT_ACC] = W(h, "sec_acc");
     float* sec_dirs = W(h, "sec_dirs"); float* sec_env = W(h, "sec_env");

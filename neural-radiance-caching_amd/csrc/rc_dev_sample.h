@@ -245,8 +245,13 @@ __device__ __forceinline__ void sample_level_ray(const RcSampleArgs& a, const US
   // --- s -> t (coord.py:259-260), cast (render.py:49-59, 106-131)
   float s_near = 0.0f, s_far = 0.0f;
   if (a.use_raydist) {
-    s_near = power_ladder(near, a.raydist_p, a.raydist_premult);
-    s_far = power_ladder(far, a.raydist_p, a.raydist_premult);
+    if (a.s_bounds) {           // one (near, far) for the whole batch: computed once by the same function
+      s_near = a.s_bounds[0];
+      s_far = a.s_bounds[1];
+    } else {
+      s_near = power_ladder(near, a.raydist_p, a.raydist_premult);
+      s_far = power_ladder(far, a.raydist_p, a.raydist_premult);
+    }
   }
   for (int e2 = lane; e2 <= S; e2 += 64) {
     const float s = s_out[e2];

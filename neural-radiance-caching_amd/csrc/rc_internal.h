@@ -76,6 +76,9 @@ struct RcSampleArgs {
   int32_t secondary;          // near replacement from the surface normal + far clamp (secondary rays)
   int32_t use_raydist;        // sample in power-ladder distance (Model.get_bg_and_raydist, models.py:183-191)
   float raydist_p, raydist_premult, eps_dot_min, far_clamp;
+  // use_raydist with ONE (near, far) for the whole batch (the material stage's secondary rays): power_ladder(near),
+  // power_ladder(far) computed once on the device (rc_launch_ladder_bounds) instead of by every wave; nullptr otherwise
+  const float* s_bounds;
 };
 void rc_launch_sample(const RcSampleArgs& a, hipStream_t stream);
 
@@ -120,6 +123,9 @@ struct RcResampleArgs {
   float* nrm_out;             // [n,3]
 };
 void rc_launch_resample(const RcResampleArgs& a, hipStream_t stream);
+// out[0] = power_ladder(near'), out[1] = power_ladder(far') with near' / far' as sample_level_ray derives them from
+// (near, far) for a secondary ray without a surface normal
+void rc_launch_ladder_bounds(float near, float far, float far_clamp, float p, float premult, float* out, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // MFMA MLP kernels

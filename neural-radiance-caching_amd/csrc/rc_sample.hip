@@ -257,6 +257,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
 
 }  // namespace
 
+__global__ void k_ladder_bounds(float near, float far, float far_clamp, float p, float premult, float* out) {
+  far = fminf(far, far_clamp);                                      // models.py:670-673 (sample_level_ray, secondary)
+  out[0] = power_ladder(near, p, premult);
+  out[1] = power_ladder(far, p, premult);
+}
+void rc_launch_ladder_bounds(float near, float far, float far_clamp, float p, float premult, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(k_ladder_bounds, dim3(1), dim3(1), 0, stream, near, far, far_clamp, p, premult, out);
+}
+
 void rc_launch_sample(const RcSampleArgs& a, hipStream_t stream) {
   if (a.n_rays <= 0) return;
   const USpec us = make_uspec(a.S, a.jitter != nullptr);
