@@ -178,7 +178,7 @@ def test_level_kernels_equal_the_separate_gather_and_mlp_kernels(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [3, 130, 768])
+@pytest.mark.parametrize("n", [1, 3, 130, 257, 768])
 def test_material_stage_is_bitwise_the_same_on_every_launch_plan(n):
     """rc_render_material on the three launch plans of rc_set_fused: 1 (default) runs the primary cache pass as the ONE
     fused launch with its per-sample results exported for the shading-point pick, 2 the launch-per-stage pass with the
