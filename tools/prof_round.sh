@@ -17,7 +17,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/staged -o staged -- $
 echo "staged trace done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/material -o material -- python $ROOT/tools/bench_material.py > $O/bench_material.txt 2> $O/material.err
 echo "material trace done"
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"; do
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
+           "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
+           "SQ_VALU_MFMA_COEXEC_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
+           "SQ_VMEM_TA_ADDR_FIFO_FULL SQ_INST_CYCLES_VMEM_RD SQ_INSTS_SALU SQ_INSTS_VALU"; do
   tag=pmc_$(echo $set | cut -d' ' -f1 | tr 'A-Z' 'a-z')
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/$tag -o p -- $B --no-transient --steps 20 --warmup 5 > /dev/null 2> $O/$tag.err
   echo "$tag done"
