@@ -764,7 +764,9 @@ def render_image_distributed(model_apply, rng, rays: Rays, config, passes=("cach
     results on its device, packs the consumed keys into one [rays_per_rank, sum(widths)] buffer and
     issues ONE all_gather per image (the reference all-gathers the whole ~45-key dict per chunk per
     repeat, internal/train_utils.py:3795-3815).  With num_repeats > 1 the repeats of a chunk are averaged on the
-    device BEFORE the gather (running mean, the update of internal/models.py:2483-2490).
+    device BEFORE the gather (running mean, the update of internal/models.py:2483-2490) -- for the
+    reference's stat_keys only (internal/models.py:2398-2401, `_STAT_KEYS`); every other key keeps the first repeat's
+    value, exactly as render_image / _render_image_device do (a mean of unit normals is not a unit normal).
 
     model_apply(rng, rays) -> {"render": {key: tensor[n, ...]}}; runs on "nccl" (= RCCL over xGMI)
     with the HIP model and on "gloo" with any CPU callable (tests).  `device`: where a rank with an empty shard
@@ -789,6 +791,7 @@ def render_image_distributed(model_apply, rng, rays: Rays, config, passes=("cach
     chunk = config.render_chunk_size
     buf = None
     first = True
+    stat_cols = None                   # [sum(widths)] bool: columns whose key the reference averages over repeats
     for idx0 in range(lo, hi, chunk):
         sub = flat.tree_map(lambda r: r[idx0: min(idx0 + chunk, hi)])
         m = min(idx0 + chunk, hi) - idx0
@@ -798,7 +801,14 @@ def render_image_distributed(model_apply, rng, rays: Rays, config, passes=("cach
             first = False
             out = model_apply(key, sub)["render"]
             cur = torch.cat([out[k].reshape(m, -1) for k in keys], dim=1)
-            mean = cur if mean is None else mean + (cur - mean) / (i_repeat + 1)
+            if mean is None:
+                mean = cur.clone() if num_repeats > 1 else cur
+                continue
+            if stat_cols is None:
+                mask = np.concatenate([np.full(widths[k], k in _STAT_KEYS) for k in keys])
+                stat_cols = torch.from_numpy(mask).to(cur.device)
+            delta = cur - mean                                          # models.py:2485-2486, stat_keys only
+            mean += torch.where(stat_cols, delta / (i_repeat + 1), torch.zeros_like(delta))
         if buf is None:
             dev = device or mean.device
             buf = torch.zeros((per, int(cols[-1])), dtype=torch.float32, device=dev)

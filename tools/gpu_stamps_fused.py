@@ -10,8 +10,18 @@ rc = rc_ext.RadianceCache(cfg, 0); rc.load_weights(nrc_amd.synthetic_weights(cfg
 rc.set_graph_mode(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 outs = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] else None
-rays = nrc_amd.synthetic_rays(n)
-f = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in rays.hot_fields().items()}
+# RC_STAMP_RAYS: random (the bench's incoherent rays, default) | tile (32x32 pixels of the 800x800 camera) | strip (a
+# 1024-pixel row strip of it, what render_image's 1024-ray chunks are)
+mode = os.environ.get("RC_STAMP_RAYS", "random")
+if mode == "random":
+    rays = nrc_amd.synthetic_rays(n)
+    f = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in rays.hot_fields().items()}
+else:
+    assert n == 1024
+    cam = nrc_amd.synthetic_camera_rays(800, 800)
+    sel = (slice(384, 416), slice(384, 416)) if mode == "tile" else (slice(400, 402), slice(0, 512))
+    f = {k: torch.from_numpy(np.ascontiguousarray(np.asarray(v)[sel].reshape(1024, -1))).cuda() for k, v in cam.hot_fields().items()}
+print("rays:", mode)
 for _ in range(5): rc.render_rays(f, None, outputs=outs) if outs else rc.render_rays(f, None)
 torch.cuda.synchronize()
 rc.lib.rc_debug_fused_stamps.restype = ctypes.c_void_p
@@ -33,7 +43,7 @@ for i, nm in enumerate(names[:11]):
 print("total median us", np.median(tot) / ghz / 1e3, "kernel span us", (d[:, 15].max() - d[:, 14].min()) / 100.0, "start skew us", (d[:, 14].max() - d[:, 14].min()) / 100.0)
 if len(sys.argv) > 3:      # JSON for profiles/fused_phase_stamps.json (bench.py's hashgrid.in_fused_kernel block)
     import json
-    json.dump({"source_hash": rc_ext.source_hash(), "n_rays": n, "clock_ghz": float(ghz),
+    json.dump({"source_hash": rc_ext.source_hash(), "n_rays": n, "rays": mode, "clock_ghz": float(ghz),
                "phases_us": {nm.split("+")[0].split("(")[0] if nm.startswith("gather") else nm: float(np.median(seg[:, i]) / ghz / 1e3) for i, nm in enumerate(names)},
                "total_us": float(np.median(tot) / ghz / 1e3),
                "how": "tools/gpu_stamps_fused.py on the -DRC_STAMPS build (make diag): s_memtime at the phase boundaries of "
