@@ -116,6 +116,7 @@ struct rc_handle {
   int n_taps = 0;
   // fused per-ray kernel for the plain cache pass (fused_mode: 0 never, 1 whenever eligible)
   int fused_mode = 1;
+  int fused_stagger = getenv("RC_FUSED_STAGGER") ? atoi(getenv("RC_FUSED_STAGGER")) : 0;   // experiment (rc_fused2.hip)
 #ifdef RC_FUSED_DIRECT_EXPERIMENT
   int fused_direct = getenv("RC_FUSED_DIRECT") ? atoi(getenv("RC_FUSED_DIRECT")) : 0;   // experiment switch (see rc_fused.hip, DIRECT)
 #else
@@ -981,7 +982,7 @@ int rc_set_profiling(rc_handle* h, int32_t enabled) {
 int rc_set_fused(rc_handle* h, int32_t mode) {
   RC_TRY
   if (!h) return RC_ERR_INVALID_ARG;
-  if (mode < 0 || mode > 2) return fail(h, RC_ERR_INVALID_ARG, "rc_set_fused: mode must be 0, 1 or 2");
+  if (mode < 0 || mode > 3) return fail(h, RC_ERR_INVALID_ARG, "rc_set_fused: mode must be 0, 1, 2 or 3");
   if (mode != h->fused_mode) drop_graphs(h);
   h->fused_mode = mode;
   return RC_OK;
@@ -1107,6 +1108,8 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     F.rgb_max = c.rgb_max; F.slf_ambient_bias = c.slf_ambient_bias;
     F.out = A.out;
     F.direct = h->fused_direct;
+    F.team = (h->fused_mode == 1 && !A.export_samples) ? 1 : 0;          // mode 3: the one-wavefront-per-ray form
+    F.stagger_cycles = h->fused_stagger;
     if (A.export_samples) {
       const std::string L2 = std::to_string(NL - 1);
       F.export_samples = 1;
@@ -1177,7 +1180,7 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     la.grid = &h->grids[l].dev; la.means = W(h, "means" + L); la.n = np; la.wstream = h->packs["dens_" + L].p;
     la.density_bias = c.density_bias; la.contract_radius = c.contract_radius; la.density = W(h, "density" + L);
     // (one ray per wave pays from ~100 rays per CU on: measured break-even of the whole pass near 32 k rays, +27 us at 1-4 k)
-    if (level_kernel && h->fused_mode == 1 && n >= 24576 && rc_level_ray_supported(h->grids[l].dev, S)) {
+    if (level_kernel && (h->fused_mode == 1 || h->fused_mode == 3) && n >= 24576 && rc_level_ray_supported(h->grids[l].dev, S)) {
       rc_launch_level_ray(la, sa, st);
       continue;
     }
@@ -1335,7 +1338,7 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_random
   }
   if (secondary && !(pass_mask & RC_PASS_NO_ENVMAP) && !h->have_envmap)
     return fail(h, RC_ERR_MISSING_WEIGHT, "missing weight: params/Cache/EnvMap/* (secondary rays composite the model-level EnvMap)");
-  const bool fused = h->fused_mode == 1 && h->fused_ok && pass_mask == RC_PASS_CACHE;
+  const bool fused = (h->fused_mode == 1 || h->fused_mode == 3) && h->fused_ok && pass_mask == RC_PASS_CACHE;
   // one workspace set per caller stream (up to 4): calls on different streams do not share buffers.  The fused kernel
   // keeps every intermediate on chip: no workspace, no set.
   const int ws_slot = fused ? 0 : ws_pick(h, st);
@@ -1540,7 +1543,7 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
   A.n = n; A.mask = RC_PASS_CACHE; A.out = *cache_out; A.slot = -1;
   // the fused kernel when the handle runs it (rc_set_fused mode 1): one launch, its per-sample results exported for
   // steps 2-3 below; bitwise the launch-per-stage pass (tests/test_gpu_parity.py)
-  A.fused = h->fused_mode == 1 && h->fused_ok && !h->profiling && c.num_samples[NL - 1] == 32;
+  A.fused = (h->fused_mode == 1 || h->fused_mode == 3) && h->fused_ok && !h->profiling && c.num_samples[NL - 1] == 32;
   A.export_samples = A.fused;
   enqueue_all(h, A, st);
 

@@ -16,30 +16,13 @@
 // rc_mlp.hip), whose reference citations apply; this file only changes where the data lives.
 // Used for the cache pass on primary rays without resampling (BASELINE configs 1, 2, 4); secondary
 // rays, resampling and the material stage use the stand-alone kernels.
-#include "rc_dev_grid.h"
-#include "rc_dev_mlp.h"
-#include "rc_dev_sample.h"
+#include "rc_fused_common.h"
 #include <type_traits>
 
 using namespace rcdev;
+using namespace rcfused;
 
 namespace {
-
-constexpr int kTileStride = 33 * 64;          // floats between the two point-tiles of levels 0/1
-constexpr int kScratch = 7 * 68;              // per-wave step-function scratch (floats)
-constexpr int kAppTmp = 33;                   // act steps [33, 49): appearance features parked during the density MLP
-constexpr int kJac = 49;                      // act steps [49, 97): d feature / d position of the level-2 density grid
-
-// fragments of the fused weight stream
-template <int KS0> struct DensFrags {
-  static constexpr int NO = KS0 == 17 ? 4 : 1;       // output rows: density (+ 3 predicted normals on the last level)
-  static constexpr int D0 = 0, D1 = 2 * KS0, DO = 2 * KS0 + 66, B1 = DO + NO * 33, B0 = B1 + 64, END = B0 + 32;
-};
-constexpr int F_L0 = 0;                              // K = 6: KS0 = 4
-constexpr int F_L1 = F_L0 + DensFrags<4>::B1;        // K = 7: KS0 = 5
-constexpr int F_L2 = F_L1 + DensFrags<5>::B1;        // K = 32: KS0 = 17, with the 96 backward fragments
-constexpr int F_SH = F_L2 + DensFrags<17>::END;
-constexpr int NF_FUSED = F_SH + ShaderFrags::COUNT;
 
 // Density MLP of a proposal level on 64 samples (two point-tiles); returns the raw density of
 // sample `lane`.  K grid features of this lane's sample are in f[].
@@ -70,44 +53,6 @@ __device__ __forceinline__ float density_level64(const WS& ws, float* act_wave, 
   // the dot product is complete on both half-waves: sample `lane` = (tile = lane >> 5, point lane & 31)
   return tile == 0 ? out[0][0] : out[1][0];
 }
-
-#ifdef RC_STAMPS
-#define RC_FSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); stamps[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define RC_FSTAMP(i) do { } while (0)
-#endif
-
-#ifdef RC_STAMPS
-#define RC_FSTAMP_NOWAIT(i) do { __builtin_amdgcn_sched_barrier(0); stamps[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define RC_FSTAMP_NOWAIT(i) do { } while (0)
-#endif
-struct RcFusedArgs {
-  const float* origins; const float* directions; const float* viewdirs; const float* near; const float* far;
-  const float* lights;
-  int64_t n;
-  const float* jitter[3];
-  RcGridDev grid[4];
-  const float* pair_table[RC_MAX_GRID_LEVELS];
-  const float* cell_table[2][RC_MAX_GRID_LEVELS];
-  const float* wstream; const float* ide_coef;
-  USpec us[3];
-  float anneal, padding, density_bias, contract_radius, bg;
-  float pct[3];
-  ShaderConsts sh;
-  rc_outputs out;
-  unsigned long long* stamps;
-  // FRONT variant (time-resolved cache): the proposal sampler only; what the launch-per-stage front end leaves in the
-  // workspace for the stages behind it, in its layouts (np = n * 32 shaded samples)
-  int32_t use_raydist; float raydist_p, raydist_premult, y_max;      // power-ladder distances (coord.py:223-260)
-  float* f_tdist;          // [n][33]
-  float* f_density;        // [np]
-  float* f_means;          // SoA [3][np]
-  float* f_normals_pred;   // SoA [3][np]
-  float* f_normals_grad;   // SoA [3][np] (GRAD) or nullptr
-  float* f_hbuf;           // [n][32 steps][64 lanes]: hidden feature in accumulator layout, one tile per ray
-  float* f_app;            // feature-major [32][np]
-};
 
 // FRONT: stop behind the last proposal level (density MLP + appearance lookup) and hand the per-sample results to the
 // stages of the time-resolved cache; the stream then ends at F_SH.
@@ -640,6 +585,11 @@ void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream) {
     return;
   }
 #endif
+  if (L.team) {
+    a.stagger_cycles = L.stagger_cycles;
+    rc_launch_fused_team(a, L.out.ptr[RC_OUT_NORMALS] != nullptr, stream);
+    return;
+  }
   if (L.out.ptr[RC_OUT_NORMALS]) hipLaunchKernelGGL(k_cache_fused<true>, grid, block, lds, stream, a);
   else hipLaunchKernelGGL(k_cache_fused<false>, grid, block, lds, stream, a);
 }
