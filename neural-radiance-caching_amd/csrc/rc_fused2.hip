@@ -164,7 +164,8 @@ __device__ __forceinline__ void dot_out_lds(const WStream& w, int q, const float
 // One proposal level's lookup + density MLP on this wave's 32 samples (rc_level.hip's LevelK::tile with the weights
 // coming through the ring): the two half-waves split the grid levels by parity.  Returns the raw density of sample j.
 template <int NL, int FB, int G>
-__device__ __forceinline__ float level_tile(const RcFusedArgs& a, const WStream& ws, float* act_tile, int lane, float cx, float cy, float cz) {
+__device__ __forceinline__ float level_tile(const RcFusedArgs& a, const WStream& ws, float* act_tile, int lane, float cx, float cy, float cz,
+                                            unsigned long long* stamp = nullptr) {
   constexpr int KS0 = (NL + 1) / 2 + 1;
   using FR = DensFrags<KS0>;
   const int hh = lane >> 5;
@@ -197,6 +198,9 @@ __device__ __forceinline__ float level_tile(const RcFusedArgs& a, const WStream&
   }
   act[(KS0 - 1) * 64] = hh == 0 ? 1.0f : 0.0f;
   lds_sync<false>();
+#ifdef RC_STAMPS
+  if (stamp) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); *stamp = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#endif
   f32x16 acc[2];
   acc[0] = zero16(); acc[1] = zero16();
   mlp_layer<2, KS0, FB + FR::D0, kNF, 4, kTW, kTCH>(ws, act, acc);
@@ -231,9 +235,27 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
   unsigned long long stamps[16];
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  if (a.stagger_cycles > 0 && blockIdx.x >= (gridDim.x >> 1)) {      // experiment: late start of the grid's second half
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
-    while (__builtin_amdgcn_s_memtime() - t_start < (unsigned long long)a.stagger_cycles) __builtin_amdgcn_s_sleep(8);
+  // Stagger (see rc_launch_fused_team): the workgroups that share a CU run the same phases at the same time -- all of
+  // them in the lookups (bound by the memory system's random-sector rate, SIMDs idle), then all of them in the matrix
+  // phases.  Every second workgroup to ARRIVE on a physical CU starts `stagger_cycles` late, so one half of the batch
+  // gathers while the other half multiplies.  Which workgroups share a CU is the dispatcher's business: the arrival
+  // counter is indexed by the hardware's own CU identity.
+  if (a.stagger_cycles > 0) {
+    int late = 0;
+    if (threadIdx.x == 0) {
+      const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID: CU_ID 11:8, SH_ID 12, SE_ID 15:13
+      const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);         // HW_REG_XCC_ID 3:0
+      const uint32_t key = ((xcc & 15u) << 8) | ((hw >> 8) & 255u);
+      late = atomicAdd(&a.cu_slots[key], 1) & 1;
+      lds_dyn[0] = __int_as_float(late);
+    }
+    __syncthreads();
+    late = __float_as_int(lds_dyn[0]);
+    __syncthreads();
+    if (late) {
+      const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+      while (__builtin_amdgcn_s_memtime() - t_start < (unsigned long long)a.stagger_cycles) __builtin_amdgcn_s_sleep(16);
+    }
   }
   RC_FSTAMP(0);
   ws_begin<kNF, kTW, kTCH>(ws);
@@ -278,7 +300,11 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
     mean_of(32 * q + j, mx, my, mz, t0, t1);
     float cx = mx, cy = my, cz = mz;
     contract3(cx, cy, cz, a.contract_radius);
-    const float raw = level_tile<6, F_L0, 0>(a, ws, act_ray + q * kTileStride, lane, cx, cy, cz);
+    const float raw = level_tile<6, F_L0, 0>(a, ws, act_ray + q * kTileStride, lane, cx, cy, cz
+#ifdef RC_STAMPS
+                                            , &stamps[2]
+#endif
+    );
     if (h == 0) x_dens[32 * q + j] = density_of(raw, cx, cy, cz, a.grid[0].bbox);
   }
   TB();
@@ -297,7 +323,11 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
     mean_of(32 * q + j, mx, my, mz, t0, t1);
     float cx = mx, cy = my, cz = mz;
     contract3(cx, cy, cz, a.contract_radius);
-    const float raw = level_tile<7, F_L1, 1>(a, ws, act_ray + q * kTileStride, lane, cx, cy, cz);
+    const float raw = level_tile<7, F_L1, 1>(a, ws, act_ray + q * kTileStride, lane, cx, cy, cz
+#ifdef RC_STAMPS
+                                            , &stamps[5]
+#endif
+    );
     if (h == 0) x_dens[32 * q + j] = density_of(raw, cx, cy, cz, a.grid[1].bbox);
   }
   TB();
@@ -679,6 +709,17 @@ void rc_launch_fused_team(const RcFusedArgs& a, bool grad, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused_team<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   dim3 grid((unsigned)((a.n + 1) / 2)), block(kTW * 64);
-  if (grad) hipLaunchKernelGGL(k_cache_fused_team<true>, grid, block, lds, stream, a);
-  else hipLaunchKernelGGL(k_cache_fused_team<false>, grid, block, lds, stream, a);
+  RcFusedArgs b = a;
+  if (b.stagger_cycles > 0) {
+    static std::atomic<int32_t*> slots{nullptr};       // one process drives one GPU (one handle per device)
+    int32_t* p = slots.load();
+    if (!p) {
+      if (hipMalloc((void**)&p, 4096 * sizeof(int32_t)) != hipSuccess || hipMemset(p, 0, 4096 * sizeof(int32_t)) != hipSuccess) p = nullptr;
+      slots.store(p);
+    }
+    b.cu_slots = p;
+    if (!p) b.stagger_cycles = 0;
+  }
+  if (grad) hipLaunchKernelGGL(k_cache_fused_team<true>, grid, block, lds, stream, b);
+  else hipLaunchKernelGGL(k_cache_fused_team<false>, grid, block, lds, stream, b);
 }

@@ -50,7 +50,8 @@ struct RcFusedArgs {
   ShaderConsts sh;
   rc_outputs out;
   unsigned long long* stamps;
-  int32_t stagger_cycles;   // rc_fused2.hip experiment: the second half of the grid starts this many cycles late (0 = off)
+  int32_t stagger_cycles;   // rc_fused2.hip: every second workgroup that arrives on a CU starts this many cycles late (0 = off)
+  int32_t* cu_slots;        // rc_fused2.hip: arrival counters per physical CU (4096 entries, zero-initialised once)
   // FRONT variant (time-resolved cache): the proposal sampler only; what the launch-per-stage front end leaves in the
   // workspace for the stages behind it, in its layouts (np = n * 32 shaded samples)
   int32_t use_raydist; float raydist_p, raydist_premult, y_max;      // power-ladder distances (coord.py:223-260)

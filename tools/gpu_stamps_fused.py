@@ -40,6 +40,14 @@ ghz = np.median(tot) / (np.median(rt) * 10)
 print("clock GHz", ghz)
 for i, nm in enumerate(names[:11]):
     print(f"  {nm:12s} median {np.median(seg[:, i]):9.0f} cyc = {np.median(seg[:, i]) / ghz / 1e3:7.2f} us   p95 {np.percentile(seg[:, i], 95) / ghz / 1e3:7.2f} us")
+if os.environ.get("RC_FUSED_STAGGER", "0") not in ("", "0"):      # two-wavefront kernel with a late half: phases per half
+    t0 = d[:, 0].astype(np.float64); base = np.percentile(t0, 2); late = (t0 - base) > 0.5 * float(os.environ["RC_FUSED_STAGGER"])
+    t0 = t0 - base + t0.min()
+    for nm2, sel in (("early", ~late), ("late", late)):
+        if sel.sum() == 0: continue
+        print(f"  [{nm2}: {int(sel.sum())} rays] start {np.median(t0[sel] - t0.min()) / ghz / 1e3:6.1f} us; " +
+              " ".join(f"{nm.split('+')[0][:9]} {np.median(seg[sel, i]) / ghz / 1e3:5.1f}" for i, nm in enumerate(names)) +
+              f"; total {np.median(tot[sel]) / ghz / 1e3:6.1f} us; end {np.median(d[sel, 11] - t0.min()) / ghz / 1e3:6.1f} us")
 print("total median us", np.median(tot) / ghz / 1e3, "kernel span us", (d[:, 15].max() - d[:, 14].min()) / 100.0, "start skew us", (d[:, 14].max() - d[:, 14].min()) / 100.0)
 if len(sys.argv) > 3:      # JSON for profiles/fused_phase_stamps.json (bench.py's hashgrid.in_fused_kernel block)
     import json
