@@ -293,8 +293,12 @@ def main():
     ap.add_argument("--no-image", action="store_true",
                     help="skip the 800x800 image line (configs[3], strong scaling over the ranks)")
     ap.add_argument("--graph-mode", type=int, default=2, help="0 eager, 1 lazy hipGraph, 2 hipGraph at once")
-    ap.add_argument("--plan", choices=("fused", "staged"), default="fused",
-                    help="fused: one launch per batch (rc_set_fused 1, default); staged: one launch per stage")
+    ap.add_argument("--plan", choices=("fused", "fused1", "staged"), default="fused",
+                    help="fused: one launch per batch, two wavefronts per ray (rc_set_fused 1, default); fused1: the same with "
+                         "one wavefront per ray (rc_set_fused 3, the round-1/2 kernel); staged: one launch per stage")
+    ap.add_argument("--runs", type=int, default=5,
+                    help="the timed region (--steps steps between two barriers) is repeated this many times in-process; "
+                         "the MEDIAN run is reported as ms_per_step / value, all runs in config.ms_per_step_runs")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent batches in flight: step i is enqueued on HIP stream i %% streams")
     ap.add_argument("--profile-mode", type=int, default=3,
@@ -338,8 +342,9 @@ def main():
     model.load_variables(weights)
     rc = model.rc
     rc.set_graph_mode(args.graph_mode)
-    fused = args.plan == "fused"
-    rc.set_fused(fused)
+    fused = args.plan in ("fused", "fused1")
+    fused_mode = {"fused": 1, "fused1": 3, "staged": 0}[args.plan]
+    rc.set_fused(fused_mode)
 
     def batch(seed):
         r = nrc_amd.synthetic_rays(RAYS_PER_BATCH, seed=seed)
@@ -381,16 +386,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # The timed region -- EXACTLY --steps steps between two (barrier + synchronize), MAX over the ranks -- is run
+    # --runs times back to back; the median run is the one reported (a 200-step region is 26 ms: one sample of a box).
+    run_s = []
+    for _ in range(max(1, args.runs)):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        run_s.append(el)
+    elapsed = sorted(run_s)[len(run_s) // 2]
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         # rendered pixels of all ranks, gathered once (image granularity), outside the step loop
         pix = torch.cat([out["rgb"], out["acc"][:, None]], dim=1)
         gathered = torch.empty((world * pix.shape[0], 4), device=dev)
@@ -415,7 +427,7 @@ def main():
     torch.cuda.synchronize()
     stage = rc.stage_times_ms()
     rc.set_profiling(0)
-    rc.set_fused(fused)
+    rc.set_fused(fused_mode)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -438,6 +450,16 @@ def main():
                             "median over the 1024 rays; the level-2 phase looks the density and the appearance grid up together)",
                     "achieved": grid_bytes / (g_us * 1e-6) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": grid_bytes / (g_us * 1e-6) / 1e9 / PEAK_HBM_GBS, "sum_phase_us": g_us}
+    # the same phases on coherent image rays (a 32x32-pixel tile / a 1024-pixel row strip of the 800x800 camera): the
+    # regime render_image's chunks are in (profiles/r03_coherent_stamps.txt)
+    coherent = {}
+    for mode in ("tile", "strip"):
+        st_c, src_c = measured_file(f"fused_phase_stamps_{mode}.json", src_hash)
+        if st_c is not None:
+            g_c = sum(st_c["phases_us"][k] for k in ("gather0", "gather1", "gather2"))
+            coherent[mode] = {"achieved": grid_bytes / (g_c * 1e-6) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": grid_bytes / (g_c * 1e-6) / 1e9 / PEAK_HBM_GBS, "sum_phase_us": g_c,
+                              "launch_us": st_c["total_us"], "source": src_c}
     res = {
         "metric": "rays/sec (1024-ray batch, 64+64 proposal + 32 shaded samples/ray), hotdog cache forward",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -449,9 +471,12 @@ def main():
                    "parallelism": f"ray-sharded x{world}",
                    "launch": "eager" if (args.profile_mode or args.graph_mode == 0 or fused) else "hipGraph",
                    "batches_in_flight": nstr,
-                   "kernel_plan": "fused: 1 launch per batch, 1 wavefront per ray" if fused else "staged: 13 launches per batch",
+                   "ms_per_step_runs": [e / args.steps * 1e3 for e in run_s],
+                   "kernel_plan": {"fused": "fused: 1 launch per batch, 2 wavefronts per ray, 2 workgroups per CU (k_cache_fused_team)",
+                                   "fused1": "fused: 1 launch per batch, 1 wavefront per ray (k_cache_fused)",
+                                   "staged": "staged: 13 launches per batch"}[args.plan],
                    "kernel_source_hash": src_hash},
-        "roofline": {"kernel": "k_cache_fused" if fused else "k_cache_shader", "bound": "mfma", "achieved": achieved_tf,
+        "roofline": {"kernel": {"fused": "k_cache_fused_team", "fused1": "k_cache_fused", "staged": "k_cache_shader"}[args.plan], "bound": "mfma", "achieved": achieved_tf,
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
                      # HBM-side bytes per launch: FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes (KiB as
                      # reported: random 4/16-byte gathers, the x2 correction for wide streaming reads does not apply);
@@ -464,7 +489,8 @@ def main():
                                 "separate pass (NOT the path `value` times)", "bound": "hbm",
                      "achieved": grid_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": grid_gbs / PEAK_HBM_GBS,
                      "sum_launch_ms": grid_ms, "algorithmic_bytes_per_batch": grid_bytes,
-                     "in_fused_kernel": in_fused, "in_fused_source": stamps_src},
+                     "in_fused_kernel": in_fused, "in_fused_source": stamps_src,
+                     "in_fused_kernel_coherent": coherent or None},
         "stage_ms_separate_pass_staged_plan": stage,
         "image": image,
     }

@@ -1524,7 +1524,7 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
   if ((rc = ws_alloc(h, "m_pts", 3 * n)) || (rc = ws_alloc(h, "m_nrm", 3 * n)) || (rc = ws_alloc(h, "m_feat", 32 * n)) ||
       (rc = ws_alloc(h, "m_mat", RC_MAT_CH * n)) || (rc = ws_alloc(h, "m_feat_all", 32 * np2)) ||
       (rc = ws_alloc(h, "m_mat_all", RC_MAT_CH * np2)) || (rc = ws_alloc(h, "l_feat", 32 * n)) ||
-      (rc = ws_alloc(h, "l_vmf", (int64_t)128 * RC_VMF_CH * n)) || (rc = ws_alloc(h, "sec_origins", 3 * nsec)) ||
+      (rc = ws_alloc(h, "l_vmf", (int64_t)128 * RC_VMF_CH * n)) || (rc = ws_alloc(h, "l_vmf_logit", (int64_t)128 * n)) || (rc = ws_alloc(h, "sec_origins", 3 * nsec)) ||
       (rc = ws_alloc(h, "sec_dirs", 3 * nsec)) || (rc = ws_alloc(h, "sec_near", nsec)) || (rc = ws_alloc(h, "sec_far", nsec)) ||
       (rc = ws_alloc(h, "sec_lights", 3 * nsec)) || (rc = ws_alloc(h, "sec_samples", RC_SMP_CH * nsec)) ||
       (rc = ws_alloc(h, "m_local_view", 3 * n)) || (rc = ws_alloc(h, "sec_rgb", 3 * nsec)) ||
@@ -1568,6 +1568,18 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     for (hipEvent_t& e : h->ev_side) RC_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   hipStream_t side = h->side_stream;
+  // Whatever way this function is left once work has been forked onto the side stream, the caller's stream is joined
+  // to it again BEFORE the workspace set is released (declared after LeaveGuard: destroyed first): an early error
+  // return must not leave side-stream kernels writing mat_out / sec_env behind a caller that believes `st` orders
+  // everything of the call.
+  struct SideJoin {
+    rc_handle* h; hipStream_t st, side; bool forked;
+    ~SideJoin() {
+      if (!forked) return;
+      if (hipEventRecord(h->ev_side[2], side) != hipSuccess || hipStreamWaitEvent(st, h->ev_side[2], 0) != hipSuccess)
+        (void)hipStreamSynchronize(side);
+    }
+  } side_join{h, st, side, false};
   // 3a. material head at the shading point (caller's stream) | 4. light sampler: 128 vMF lobes per shading point (side
   // stream) -- both read only the shading point; then 3b. the material head on all samples and the material-only
   // composite (side stream)
@@ -1578,13 +1590,14 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     ma.min_roughness = c.min_roughness;
     RC_HIP(h, hipEventRecord(h->ev_side[0], st));                 // shading points, means / weights of the last level are in place
     RC_HIP(h, hipStreamWaitEvent(side, h->ev_side[0], 0));
+    side_join.forked = true;
     rc_launch_hashgrid(h->grids[5].dev, W(h, "m_pts"), 0, n, W(h, "l_feat"), 0, 32, c.contract_radius, nullptr, side);
     RcLightHeadArgs la{};
     la.n = n; la.feat = W(h, "l_feat");
     la.w0 = raw("params/LightSampler/layers_0", "kernel"); la.b0 = raw("params/LightSampler/layers_0", "bias");
     la.w1 = raw("params/LightSampler/layers_1", "kernel"); la.b1 = raw("params/LightSampler/layers_1", "bias");
     la.w2 = raw("params/LightSampler/output_layer", "kernel"); la.b2 = raw("params/LightSampler/output_layer", "bias");
-    la.pts = W(h, "m_pts"); la.noise = mr->vmf_noise; la.vmf_scale = c.vmf_scale; la.vmf = W(h, "l_vmf");
+    la.pts = W(h, "m_pts"); la.noise = mr->vmf_noise; la.vmf_scale = c.vmf_scale; la.vmf = W(h, "l_vmf"); la.vmf_logit = W(h, "l_vmf_logit");
     rc_launch_light_head(la, side);
     RC_HIP(h, hipEventRecord(h->ev_side[3], side));
     rc_launch_hashgrid(h->grids[4].dev, W(h, "means" + LL), 1, np2, W(h, "m_feat_all"), 0, 32, c.contract_radius, nullptr, side);
@@ -1603,7 +1616,7 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     RcBrdfSampleArgs sa{};
     sa.n = n; sa.Ks = Ks; sa.Kd = Kd; sa.Kc = Kc;
     sa.pts = W(h, "m_pts"); sa.nrm = W(h, "m_nrm"); sa.viewdirs = rays->viewdirs; sa.lights = rays->lights;
-    sa.mat = W(h, "m_mat"); sa.vmf = W(h, "l_vmf");
+    sa.mat = W(h, "m_mat"); sa.vmf = W(h, "l_vmf"); sa.vmf_logit = W(h, "l_vmf_logit");
     sa.spec_u1 = mr->spec_u1; sa.spec_u2 = mr->spec_u2; sa.cos_u1 = mr->cos_u1; sa.cos_u2 = mr->cos_u2;
     sa.vmf_lobe = mr->vmf_lobe; sa.vmf_v = mr->vmf_v; sa.vmf_tmp = mr->vmf_tmp; sa.vmf_lobe_gumbel = mr->vmf_lobe_gumbel;
     sa.normal_eps = c.secondary_normal_eps; sa.near = c.secondary_near; sa.far = c.secondary_far;
@@ -1643,6 +1656,7 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     enqueue_all(h, B, st);
     h->ws_prefix = "";
     RC_HIP(h, hipStreamWaitEvent(st, h->ev_side[2], 0));          // join: everything of this call is ordered on st again
+    side_join.forked = false;
   }
   // 7. Monte-Carlo BRDF integration + MaterialIntegrator composite
   {

@@ -222,6 +222,7 @@ struct RcLightHeadArgs {
   const float* w0; const float* b0; const float* w1; const float* b1; const float* w2; const float* b2;
   const float* pts; const float* noise;   // [n,3], [n,128,3]
   float vmf_scale; float* vmf;         // [n,128,RC_VMF_CH]
+  float* vmf_logit;                    // [n,128]: the lobe logits as the softmax sees them (the categorical lobe draw takes these)
 };
 void rc_launch_light_head(const RcLightHeadArgs& a, hipStream_t st);
 
@@ -230,7 +231,8 @@ struct RcBrdfSampleArgs {
   const float* pts; const float* nrm; const float* viewdirs; const float* lights; const float* mat; const float* vmf;
   const float* spec_u1; const float* spec_u2; const float* cos_u1; const float* cos_u2;
   const int32_t* vmf_lobe; const float* vmf_v; const float* vmf_tmp;
-  const float* vmf_lobe_gumbel;   // [n,128] or nullptr: lobe = argmax(log weight + gumbel) when vmf_lobe is nullptr
+  const float* vmf_lobe_gumbel;   // [n,128] or nullptr: lobe = argmax(logit + gumbel) when vmf_lobe is nullptr
+  const float* vmf_logit;         // [n,128] lobe logits of the light head (read only for that draw)
   float normal_eps, near, far;
   float* sec_origins; float* sec_dirs; float* sec_near; float* sec_far; float* sec_lights;   // [n*(Ks+Kd), .]
   float* samples;       // [n, Ks+Kd, RC_SMP_CH]
@@ -400,6 +402,21 @@ void rc_launch_prng_fill(const RcPrngArgs& a, hipStream_t stream);
 
 // Kernel attributes (dynamic-LDS limit) are per device: true the first time the calling thread's current device
 // shows up for this `mask` (one mask per kernel), so a process driving several GPUs sets them on each.
+// CU count of the calling thread's current device, asked once per device (it sits on the launch path of the persistent
+// level kernels).
+inline int rc_device_cus() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int v = cached[dev & 63].load(std::memory_order_relaxed);
+  if (v <= 0) {
+    v = 256;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cached[dev & 63].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
 inline bool rc_first_use_on_device(std::atomic<uint64_t>& mask) {
   int dev = 0;
   (void)hipGetDevice(&dev);

@@ -204,17 +204,45 @@ __global__ __launch_bounds__(LevelCfg<F>::W * 64) void k_level_ray(RcLevelRayKAr
   }
 }
 
+// The level kernels keep a level's whole weight stream resident: up to ~145 KB of dynamic LDS, an opt-in per kernel and
+// device.  `refused` remembers a device that turned it down: rc_level_supported then answers false there and the plan
+// falls back to the separate gather / MLP kernels instead of failing at the launch.
+std::atomic<uint64_t> g_level_refused{0};
+
+template <class K>
+bool level_prepare(K kernel, int lds, std::atomic<uint64_t>& prepared) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (rc_first_use_on_device(prepared)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      (void)hipGetLastError();
+      g_level_refused.fetch_or(bit);
+    }
+  }
+  return (g_level_refused.load() & bit) == 0;
+}
+
+template <int F, int NL>
+bool prepare_level() {
+  using LK = LevelK<F, NL>;
+  static std::atomic<uint64_t> prepared{0};
+  return level_prepare(&k_level<F, NL>, (LK::kResFloats + LK::W * kLvActSteps * 64) * (int)sizeof(float), prepared);
+}
+template <int F, int NL, int S>
+bool prepare_level_ray() {
+  using LK = LevelK<F, NL>;
+  static std::atomic<uint64_t> prepared{0};
+  return level_prepare(&k_level_ray<F, NL, S>, (LK::kResFloats + LK::W * (kLvActSteps * 64 + kLvSampFloats)) * (int)sizeof(float), prepared);
+}
+
 template <int F, int NL>
 void launch_level(const RcLevelKArgs& a, hipStream_t stream) {
   using LK = LevelK<F, NL>;
   constexpr int W = LK::W;
   const int lds = (LK::kResFloats + W * kLvActSteps * 64) * (int)sizeof(float);
-  static std::atomic<uint64_t> prepared{0};
-  if (rc_first_use_on_device(prepared))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_level<F, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  int dev = 0, cus = 256;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  (void)prepare_level<F, NL>();
+  const int cus = rc_device_cus();
   const int64_t tiles = (a.n + 31) / 32;
   const int64_t want = (tiles + W - 1) / W;
   dim3 grid((unsigned)(want < cus ? want : cus)), block(W * 64);
@@ -226,12 +254,8 @@ void launch_level_ray(const RcLevelRayKArgs& a, hipStream_t stream) {
   using LK = LevelK<F, NL>;
   constexpr int W = LK::W;
   const int lds = (LK::kResFloats + W * (kLvActSteps * 64 + kLvSampFloats)) * (int)sizeof(float);
-  static std::atomic<uint64_t> prepared{0};
-  if (rc_first_use_on_device(prepared))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_level_ray<F, NL, S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  int dev = 0, cus = 256;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  (void)prepare_level_ray<F, NL, S>();
+  const int cus = rc_device_cus();
   const int64_t want = (a.sa.n_rays + W - 1) / W;
   dim3 grid((unsigned)(want < cus ? want : cus)), block(W * 64);
   hipLaunchKernelGGL((k_level_ray<F, NL, S>), grid, block, lds, stream, a);
@@ -241,7 +265,10 @@ void launch_level_ray(const RcLevelRayKArgs& a, hipStream_t stream) {
 
 // true when (F, number of levels) is one of the compiled shapes
 bool rc_level_supported(const RcGridDev& g) {
-  return (g.num_features == 1 && (g.num_levels == 6 || g.num_levels == 7)) || (g.num_features == 4 && g.num_levels == 8);
+  if (g.num_features == 1 && g.num_levels == 6) return prepare_level<1, 6>() && prepare_level_ray<1, 6, 64>();
+  if (g.num_features == 1 && g.num_levels == 7) return prepare_level<1, 7>() && prepare_level_ray<1, 7, 64>();
+  if (g.num_features == 4 && g.num_levels == 8) return prepare_level<4, 8>() && prepare_level_ray<4, 8, 32>();
+  return false;
 }
 
 // sampling + level as one launch: supported shapes of rc_level_supported with 64 (F = 1) or 32 (F = 4) samples per ray

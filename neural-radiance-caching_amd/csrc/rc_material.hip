@@ -195,6 +195,7 @@ __global__ __launch_bounds__(128) void k_light_head(RcLightHeadArgs a) {
   const float wgt = e / s_red[0];
   float* o = a.vmf + (p * 128 + t) * RC_VMF_CH;
   o[0] = m.x; o[1] = m.y; o[2] = m.z; o[3] = kappa; o[4] = wgt;
+  a.vmf_logit[p * 128 + t] = logit;
 }
 
 // eval_vmf (render_utils.py:1335-1347) with inverse_render.math.safe_exp = exp(min(x, 80))
@@ -221,8 +222,9 @@ __global__ __launch_bounds__(256) void k_brdf_sample(RcBrdfSampleArgs a) {
   __syncthreads();
   const float* vm = s_vmf[wave];
   const float* den = s_den[wave];
-  // sample_vmf_vars (render_utils.py:1357-1372): ONE lobe per point, given or drawn here as argmax_j(logit_j + g_j)
-  // (= jax.random.categorical; log of the softmax weight differs from the logit by a constant of the point)
+  // sample_vmf_vars (render_utils.py:1357-1372): ONE lobe per point, given or drawn here as argmax_j(logit_j + g_j) on
+  // the RAW logits of the light head, exactly what jax.random.categorical(key, logits=vars[2]) does (render_utils.py:
+  // 1358-1362) -- not on log(softmax), whose rounding and underflow clamp could flip a near-tie
   int lobe;
   if (a.vmf_lobe) {
     lobe = a.vmf_lobe[r];
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void k_brdf_sample(RcBrdfSampleArgs a) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int jj = lane + 64 * q;
-      const float kq = logf(fmaxf(vm[jj * RC_VMF_CH + 4], RC_TINY)) + a.vmf_lobe_gumbel[r * 128 + jj];
+      const float kq = a.vmf_logit[r * 128 + jj] + a.vmf_lobe_gumbel[r * 128 + jj];
       if (kq > key) { key = kq; best = jj; }
     }
 #pragma unroll

@@ -302,7 +302,12 @@ class Model:
         MaterialModel.resample_render (stage material_light_from_scratch_resample; internal/models.py:1144-1254,
         1398-1694).  `rng`: the dict of explicit random tensors (see rc_material_randoms in include/rc_abi.h;
         oracle-compatible generator: oracle.material_ref.draw_randoms), or a uint32[2] key, from which the tensors are
-        derived at the reference's split sites (prng.material_pass_randoms)."""
+        derived at the reference's split sites (prng.material_pass_randoms).
+
+        NOT parity-verified: the threefry primitives are pinned by published known answers, but the ~30 split sites
+        material_pass_randoms restates by hand have never been compared with a jax run (none is possible in this
+        pipeline): a mis-ordered split would yield a different, equally valid-looking stream.  Parity claims of the
+        material stage are made on explicit random tensors only."""
         import torch
 
         n_rays = int(np.prod(np.shape(rays.origins if isinstance(rays, Rays) else rays["origins"])[:-1]))

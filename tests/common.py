@@ -13,13 +13,13 @@ def weights_np(density_shift=0.0, seed=1):
     return nrc_amd.synthetic_weights(nrc_amd.hotdog_config(), seed=seed, density_shift=density_shift)
 
 
-@functools.lru_cache(maxsize=2)
-def weights_material_np(smooth=False):
+@functools.lru_cache(maxsize=3)
+def weights_material_np(smooth=False, seed=1):
     """Cache + material + light weights.  smooth=True: table amplitude 0.2 * 0.5**level (equal spatial
     gradient per level) -- removes the chaotic amplification of one-ulp position differences that random
     fine-level tables cause, so the two implementations can be compared tightly."""
     kw = dict(level_decay=0.5, table_range=0.2) if smooth else {}
-    return nrc_amd.synthetic_weights(nrc_amd.hotdog_config(), passes=("cache", "material"), **kw)
+    return nrc_amd.synthetic_weights(nrc_amd.hotdog_config(), passes=("cache", "material"), seed=seed, **kw)
 
 
 def to_torch(w, dtype=None):

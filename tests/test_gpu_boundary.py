@@ -226,3 +226,34 @@ def test_checkpoint_round_trip_into_rc_load_weights(tmp_path):
     got = m2.apply(None, None, rays)["render"]
     for k, v in want.items():
         assert torch.equal(got[k], v), k
+
+
+def test_independent_flax_checkpoint_renders_like_the_oracle(tmp_path):
+    """SURVEY 8(f) rank 2 pinned to something other than this package's own writer: tests/golden/make_flax_checkpoint.py
+    assembles `checkpoint_25000` with the msgpack package alone -- the full hotdog inventory at real shapes, tables
+    chunked -- then checkpoint.load_params(prefixes=["params/Cache"]) -> rc_load_weights -> render, compared with the
+    ORACLE fed the original arrays (1e-4).  Parameter names stay the inferred ones (DESIGN: unverified against a real
+    Flax file).  Reference: internal/train_utils.py:4035-4088, engine/trainer.py:2054-2066."""
+    import importlib.util
+    from nrc_amd import checkpoint
+    spec = importlib.util.spec_from_file_location("make_flax_checkpoint", os.path.join(os.path.dirname(__file__), "golden", "make_flax_checkpoint.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    w = common.weights_material_np(False)                    # cache + material + light tensors, seed 1 (= common.weights_np for the cache)
+    path = mk.assemble(w, str(tmp_path), 25000, max_chunk_bytes=4 << 20)
+    assert os.path.basename(checkpoint.latest_checkpoint(str(tmp_path))) == "checkpoint_25000" and path.endswith("checkpoint_25000")
+    flat = checkpoint.load_params(str(tmp_path), prefixes=["params/Cache"])
+    assert set(flat) == {k for k in w if k.startswith("params/Cache")}
+    cfg = nrc_amd.hotdog_config()
+    m = M.Model(cfg, 0)
+    m.load_variables(flat)
+    n = 256
+    rays = nrc_amd.synthetic_rays(n)
+    got = m.apply(None, None, rays)["render"]
+    torch.cuda.synchronize()
+    ref = common.oracle_cache(n)["render"]                  # the oracle on common.weights_np(): the same cache arrays
+    for k in common.weights_np():
+        assert np.array_equal(common.weights_np()[k], w[k]), k
+    for k in ("rgb", "acc"):
+        d = float((got[k].cpu() - ref[k].reshape(got[k].shape)).abs().max())
+        assert d <= 1e-4, (k, d)

@@ -37,6 +37,8 @@ python tools/prof_to_json.py $O $O/pmc_k_cache_fused.json
 python tools/pmc_table.py $O "mat_*" > $O/material_pmc_counters.txt
 if [ -f tools/diag/librc_hip.so ]; then
   python tools/gpu_stamps_fused.py 1024 "" $O/fused_phase_stamps.json > $O/fused_phase_stamps.txt
+  RC_STAMP_RAYS=tile python tools/gpu_stamps_fused.py 1024 "" $O/fused_phase_stamps_tile.json > $O/fused_phase_stamps_tile.txt
+  RC_STAMP_RAYS=strip python tools/gpu_stamps_fused.py 1024 "" $O/fused_phase_stamps_strip.json > $O/fused_phase_stamps_strip.txt
   echo "stamps done"
 fi
 find $O -name "*.csv" | sort

@@ -20,7 +20,7 @@ from nrc_amd import rc_ext  # noqa: E402
 
 def main():
     prof, out = sys.argv[1], sys.argv[2]
-    kernel = sys.argv[3] if len(sys.argv) > 3 else "k_cache_fused<true, false, false, false>"
+    kernel = sys.argv[3] if len(sys.argv) > 3 else "k_cache_fused_team<true>"
     acc = defaultdict(list)
     for p in glob.glob(os.path.join(prof, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(p)):
