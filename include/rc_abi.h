@@ -281,14 +281,17 @@ int rc_set_profiling(rc_handle* h, int32_t mode);
  * 2 = capture on first sight.  Applies to the launch-per-stage plan; the one-launch fused plan (rc_set_fused) is always
  * launched plainly (a one-node graph replays with a larger gap between launches than a plain launch). */
 int rc_set_graph_mode(rc_handle* h, int32_t mode);
-/* Kernel plan.  1 (default): the plain cache pass (pass_mask == RC_PASS_CACHE) is one fused launch per batch, one
- * wavefront per ray, all intermediates on chip (no workspace: rc_workspace_ptr then has nothing to show); every other
- * pass runs one launch per stage, where a proposal level whose samples only hand their density on is ONE launch
- * (grid lookup + density MLP, weights resident in LDS; from 24 576 rays on also the level's sampling, one ray per
- * wave), and rc_render_material renders its primary rays with the fused launch.  2: like 1 with the plain cache pass on
- * the launch-per-stage plan too and the sampling always in its own kernel.  0: the plain launch-per-stage plan everywhere, grid lookup and density MLP as separate kernels
- * (materialises sdist/tdist/means/features/density/weights per level in the workspace).  All plans evaluate the same
- * arithmetic in the same order: results are bitwise equal
+/* Kernel plan.  1 (default): the plain cache pass (pass_mask == RC_PASS_CACHE) is one fused launch per batch, all
+ * intermediates on chip (no workspace: rc_workspace_ptr then has nothing to show) -- TWO wavefronts per ray in 4-wave
+ * workgroups of two rays, two workgroups per CU (csrc/rc_fused2.hip); every other pass runs one launch per stage, where
+ * a proposal level whose samples only hand their density on is ONE launch (grid lookup + density MLP, weights resident
+ * in LDS; from 24 576 rays on also the level's sampling, one ray per wave), and rc_render_material renders its primary
+ * rays with the fused launch (one wavefront per ray, per-sample results exported).  3: like 1 with the plain cache pass
+ * on the one-wavefront-per-ray form of the fused kernel (csrc/rc_fused.hip, the round-1/2 kernel).  2: like 1 with the
+ * plain cache pass on the launch-per-stage plan too and the sampling always in its own kernel.  0: the plain
+ * launch-per-stage plan everywhere, grid lookup and density MLP as separate kernels (materialises
+ * sdist/tdist/means/features/density/weights per level in the workspace).  All plans evaluate the same arithmetic in
+ * the same order: results are bitwise equal
  * (internal/models.py:1237-1386 / sampling.py:155-353 / nerf.py:426-693). */
 int rc_set_fused(rc_handle* h, int32_t mode);
 int rc_stage_count(void);

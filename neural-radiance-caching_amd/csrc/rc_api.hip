@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "rc_internal.h"
+#include "rc_pack_host.h"
 
 void rc_launch_hashgrid_src(const RcGridDev& g, const float* points, int soa_in, const int32_t* src, int64_t n_src,
                             int64_t n, float* out, int feature_major, int64_t ldo, float contract_radius,
@@ -24,6 +25,8 @@ void rc_launch_hashgrid_src(const RcGridDev& g, const float* points, int soa_in,
 int rc_shader_lds_bytes();
 int rc_weight_chunk_floats();
 void rc_shader_prepare();
+
+using namespace rcpack;
 
 namespace {
 
@@ -35,12 +38,6 @@ enum Stage {
 };
 const char* kStageNames[ST_COUNT] = {"sample0", "grid0", "mlp0", "sample1", "grid1", "mlp1", "sample2",
                                      "grid2", "mlp2", "resample", "grid_app", "shader", "composite"};
-
-struct HostLayer {
-  std::vector<float> kernel, bias;
-  int in = 0, out = 0;
-  bool have_kernel = false, have_bias = false;
-};
 
 struct DevBuf {
   float* p = nullptr;
@@ -116,6 +113,7 @@ struct rc_handle {
   int n_taps = 0;
   // fused per-ray kernel for the plain cache pass (fused_mode: 0 never, 1 whenever eligible)
   int fused_mode = 1;
+  RcFusedLaunch fused_tmpl{};      // launch descriptor of the fused plan, resolved at repack (build_fused_template)
   int fused_stagger = getenv("RC_FUSED_STAGGER") ? atoi(getenv("RC_FUSED_STAGGER")) : 0;   // experiment (rc_fused2.hip)
 #ifdef RC_FUSED_DIRECT_EXPERIMENT
   int fused_direct = getenv("RC_FUSED_DIRECT") ? atoi(getenv("RC_FUSED_DIRECT")) : 0;   // experiment switch (see rc_fused.hip, DIRECT)
@@ -272,86 +270,6 @@ std::map<std::string, std::pair<int, int>> dense_inventory(const rc_config& c, c
   return m;
 }
 
-// ---------------------------------------------------------------------------------------------
-// MFMA fragment packing
-// ---------------------------------------------------------------------------------------------
-struct Step { int row[2]; };               // >= 0 input row, -1 zero, -2 bias
-struct Col {
-  const HostLayer* L = nullptr;            // nullptr -> zero column
-  int col = 0;
-  int row_off = 0;
-  bool bias_ok = true;
-};
-using Tile = std::array<Col, 32>;
-
-inline int acc_feat(int t, int r, int h) { return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-void steps_natural(std::vector<Step>& s, int K, int base) {
-  for (int i = 0; i < (K + 1) / 2; ++i) s.push_back({{base + 2 * i, (2 * i + 1 < K) ? base + 2 * i + 1 : -1}});
-}
-void steps_acc(std::vector<Step>& s, int ntiles, int base) {
-  for (int t = 0; t < ntiles; ++t)
-    for (int r = 0; r < 16; ++r) s.push_back({{base + acc_feat(t, r, 0), base + acc_feat(t, r, 1)}});
-}
-void step_bias(std::vector<Step>& s) { s.push_back({{-2, -1}}); }
-
-Tile tile_full(const HostLayer* L, int t, int row_off = 0, bool bias_ok = true) {
-  Tile tl;
-  for (int i = 0; i < 32; ++i) {
-    const int c = 32 * t + i;
-    if (c < L->out) tl[i] = Col{L, c, row_off, bias_ok};
-  }
-  return tl;
-}
-// Output `regs[r]` lands in accumulator register r of BOTH half-waves.
-Tile tile_by_reg(const std::vector<Col>& regs) {
-  Tile tl;
-  for (int i = 0; i < 32; ++i) {
-    const int r = (i & 3) + 4 * (i >> 3);
-    if (r < (int)regs.size()) tl[i] = regs[r];
-  }
-  return tl;
-}
-
-// Fragments of dot_out (rc_dev_mlp.h): per output, per tile, per accumulator register the weight of the feature that
-// register holds on each half-wave; then one bias fragment per output.
-std::vector<float> pack_dot(const std::vector<Col>& outs, int ntiles) {
-  std::vector<float> v;
-  for (const Col& c : outs)
-    for (int t = 0; t < ntiles; ++t)
-      for (int r = 0; r < 16; ++r)
-        for (int lane = 0; lane < 64; ++lane) {
-          const int row = acc_feat(t, r, lane >> 5) + c.row_off;
-          v.push_back((c.L && row < c.L->in) ? c.L->kernel[(size_t)row * c.L->out + c.col] : 0.0f);
-        }
-  for (const Col& c : outs)
-    for (int lane = 0; lane < 64; ++lane) v.push_back(c.L ? c.L->bias[c.col] : 0.0f);
-  return v;
-}
-
-std::vector<float> pack(const std::vector<Step>& steps, const std::vector<Tile>& tiles) {
-  const size_t NT = tiles.size();
-  std::vector<float> out(steps.size() * NT * 64, 0.0f);
-  for (size_t s = 0; s < steps.size(); ++s)
-    for (size_t t = 0; t < NT; ++t)
-      for (int lane = 0; lane < 64; ++lane) {
-        const int h = lane >> 5, i = lane & 31;
-        const Col& c = tiles[t][i];
-        float v = 0.0f;
-        if (c.L) {
-          const int row = steps[s].row[h];
-          if (row == -2) {
-            if (c.bias_ok) v = c.L->bias[c.col];
-          } else if (row >= 0) {
-            const int rr = row + c.row_off;
-            if (rr < c.L->in) v = c.L->kernel[(size_t)rr * c.L->out + c.col];
-          }
-        }
-        out[(s * NT + t) * 64 + lane] = v;
-      }
-  return out;
-}
-
 void append(std::vector<float>& dst, const std::vector<float>& v) { dst.insert(dst.end(), v.begin(), v.end()); }
 // The kernels pull the stream in whole chunks: pad with zero fragments.
 std::vector<float> pad_stream(std::vector<float> v) {
@@ -369,27 +287,6 @@ int upload(rc_handle* h, const std::string& key, const std::vector<float>& v) {
   }
   RC_HIP(h, hipMemcpy(b.p, v.data(), b.bytes, hipMemcpyHostToDevice));
   return RC_OK;
-}
-
-// ref_utils.py:75-153 coefficient table for deg_view = 5, rounded to float32 like `mat` is.
-double fact(int n) { double f = 1; for (int i = 2; i <= n; ++i) f *= i; return f; }
-double gen_binom(double a, int k) { double p = 1; for (int j = 0; j < k; ++j) p *= (a - j); return p / fact(k); }
-double sph_coeff(int l, int m, int k) {
-  const double al = ((m & 1) ? -1.0 : 1.0) * pow(2.0, l) * fact(l) / fact(k) / fact(l - k - m) *
-                    gen_binom(0.5 * (l + k + m - 1.0), l);
-  return sqrt((2.0 * l + 1.0) * fact(l - m) / (4.0 * M_PI * fact(l + m))) * al;
-}
-void build_ide_table(RcIdeTable& tb) {
-  memset(&tb, 0, sizeof(tb));
-  int i = 0;
-  for (int d = 0; d < 5; ++d) {
-    const int l = 1 << d;
-    for (int m = 0; m <= l; ++m, ++i) {
-      tb.m[i] = m;
-      tb.sigma[i] = (float)(0.5 * l * (l + 1));
-      for (int k = 0; k <= l - m; ++k) tb.coef[i][k] = (float)sph_coeff(l, m, k);
-    }
-  }
 }
 
 const HostLayer* need(rc_handle* h, const std::string& path, std::string& missing) {
@@ -470,6 +367,25 @@ int build_fused_tables(rc_handle* h) {
   }
   RC_HIP(h, hipDeviceSynchronize());
   return RC_OK;
+}
+
+// The per-batch launch descriptor of the fused plan with every pointer and constant that only changes with the weights.
+void build_fused_template(rc_handle* h) {
+  const rc_config& c = h->cfg;
+  RcFusedLaunch F{};
+  for (int l = 0; l < 3; ++l) F.num_samples[l] = c.num_samples[l];
+  for (int g = 0; g < 4; ++g) F.grid[g] = &h->grids[g].dev;
+  for (int l = 0; l < h->grids[2].dev.num_levels; ++l) F.pair_table[l] = h->packs["pair_" + std::to_string(l)].p;
+  for (int g = 0; g < 2; ++g)
+    for (int l = 0; l < h->grids[g].dev.num_levels; ++l)
+      F.cell_table[g][l] = h->grids[g].dev.lvl[l].dense ? h->packs["cell" + std::to_string(g) + "_" + std::to_string(l)].p : nullptr;
+  F.wstream = h->packs["fused"].p; F.ide_coef = h->ide_table.p;
+  F.anneal = c.anneal; F.padding = c.resample_padding; F.density_bias = c.density_bias;
+  F.contract_radius = c.contract_radius; F.bg = c.bg_intensity;
+  for (int i = 0; i < 3; ++i) F.pct[i] = c.percentiles[i];
+  F.roughness_bias = c.roughness_bias; F.irradiance_bias = c.irradiance_bias; F.ambient_bias = c.ambient_irradiance_bias;
+  F.rgb_max = c.rgb_max; F.slf_ambient_bias = c.slf_ambient_bias;
+  h->fused_tmpl = F;
 }
 
 int repack_transient(rc_handle* h);
@@ -554,26 +470,8 @@ int repack(rc_handle* h) {
     std::vector<Step> s;
     // The shader bottleneck is linear and only feeds linear layers: fold it (fp64 products) into SLF layer_0, the
     // input part of SLF layer_bottleneck and integrated_brdf_layers_0 (see rc_dev_mlp.h, kShActSteps).
-    const int FE = bott->in, BW = bott->out;                 // 96, 128
-    auto fold = [&](const HostLayer* L, int row0, int extra_rows) {
-      // rows [row0, row0 + BW) of L consume the bottleneck; the following `extra_rows` rows are kept as they are
-      HostLayer f;
-      f.in = FE + extra_rows; f.out = L->out;
-      f.kernel.assign((size_t)f.in * f.out, 0.0f); f.bias.assign(f.out, 0.0f);
-      f.have_kernel = f.have_bias = true;
-      for (int o = 0; o < L->out; ++o) {
-        for (int i = 0; i < FE; ++i) {
-          double a = 0.0;
-          for (int m = 0; m < BW; ++m) a += (double)bott->kernel[(size_t)i * BW + m] * (double)L->kernel[(size_t)(row0 + m) * L->out + o];
-          f.kernel[(size_t)i * f.out + o] = (float)a;
-        }
-        double b = 0.0;
-        for (int m = 0; m < BW; ++m) b += (double)bott->bias[m] * (double)L->kernel[(size_t)(row0 + m) * L->out + o];
-        f.bias[o] = (float)b;                                 // the layer's own bias is added where it is packed
-        for (int e = 0; e < extra_rows; ++e) f.kernel[(size_t)(FE + e) * f.out + o] = L->kernel[(size_t)(row0 + BW + e) * L->out + o];
-      }
-      return f;
-    };
+    const int FE = bott->in;                                 // 96 (the bottleneck is 96 -> 128)
+    auto fold = [&](const HostLayer* L, int row0, int extra_rows) { return rcpack::fold_linear(*bott, *L, row0, extra_rows); };
     HostLayer l0f = fold(l0, 0, 72), lbf = fold(lb, 128, 72), i0f = fold(i0, 0, 1);
     for (int o = 0; o < l0->out; ++o) l0f.bias[o] = (float)((double)l0f.bias[o] + (double)l0->bias[o]);
     for (int o = 0; o < lb->out; ++o) lbf.bias[o] = (float)((double)lbf.bias[o] + (double)lb->bias[o]);
@@ -683,6 +581,7 @@ int repack(rc_handle* h) {
     h->ide_table.bytes = sizeof(tb);
     RC_HIP(h, hipMemcpy(h->ide_table.p, &tb, sizeof(tb), hipMemcpyHostToDevice));
   }
+  if (h->fused_ok) build_fused_template(h);
   h->packed_dirty = false;
   return RC_OK;
 }
@@ -755,7 +654,45 @@ int ensure_workspace(rc_handle* h, int64_t n) {
   return RC_OK;
 }
 
+// roctx ranges around the stages (tracing), for `rocprofv3 --marker-trace`.  The marker library is resolved at run
+// time and only when RC_ROCTX=1 is set (no link dependency, nothing on the launch path otherwise); a range covers the
+// host-side enqueue of a stage -- the kernels run asynchronously and carry their own names in the kernel trace.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  bool tried = false, open = false;
+};
+Roctx g_roctx;
+bool roctx_on() {
+  if (!g_roctx.tried) {
+    g_roctx.tried = true;
+    const char* env = getenv("RC_ROCTX");
+    if (env && atoi(env) != 0) {
+      void* lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+      if (lib) {
+        g_roctx.push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+        g_roctx.pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        if (!g_roctx.push || !g_roctx.pop) { g_roctx.push = nullptr; g_roctx.pop = nullptr; }
+      }
+    }
+  }
+  return g_roctx.push != nullptr;
+}
+// close the open stage range (if any) and open `name` (nullptr: only close)
+void roctx_stage(const char* name) {
+  if (!roctx_on()) return;
+  if (g_roctx.open) { (void)g_roctx.pop(); g_roctx.open = false; }
+  if (name) { (void)g_roctx.push(name); g_roctx.open = true; }
+}
+struct RoctxScope {       // a whole ABI call
+  bool on;
+  explicit RoctxScope(const char* name) : on(roctx_on()) { if (on) (void)g_roctx.push(name); }
+  ~RoctxScope() { if (on) { roctx_stage(nullptr); (void)g_roctx.pop(); } }
+};
+
 void stage_mark(rc_handle* h, int slot, int idx, hipStream_t s) {
+  roctx_stage(idx < ST_COUNT ? kStageNames[idx] : nullptr);
   if (slot < 0) return;
   if (h->profiling >= 2 && idx != ST_SHADER && idx != ST_SHADER + 1) return;
   (void)hipEventRecord(h->ev[slot][idx], s);
@@ -1092,20 +1029,11 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
                     !A.out.ptr[RC_OUT_NORMALS];
   const int slot = A.slot;
   if (A.fused) {
-    RcFusedLaunch F{};
+    // everything of the launch that only changes when weights are (re)packed was resolved then (fused_template): no
+    // string keys, no map lookups on the per-batch path
+    RcFusedLaunch F = h->fused_tmpl;
     F.rays = A.rays; F.n = n;
-    for (int l = 0; l < 3; ++l) { F.jitter[l] = rnd ? rnd->jitter[l] : nullptr; F.num_samples[l] = c.num_samples[l]; }
-    for (int g = 0; g < 4; ++g) F.grid[g] = &h->grids[g].dev;
-    for (int l = 0; l < h->grids[2].dev.num_levels; ++l) F.pair_table[l] = h->packs["pair_" + std::to_string(l)].p;
-    for (int g = 0; g < 2; ++g)
-      for (int l = 0; l < h->grids[g].dev.num_levels; ++l)
-        F.cell_table[g][l] = h->grids[g].dev.lvl[l].dense ? h->packs["cell" + std::to_string(g) + "_" + std::to_string(l)].p : nullptr;
-    F.wstream = h->packs["fused"].p; F.ide_coef = h->ide_table.p;
-    F.anneal = c.anneal; F.padding = c.resample_padding; F.density_bias = c.density_bias;
-    F.contract_radius = c.contract_radius; F.bg = c.bg_intensity;
-    for (int i = 0; i < 3; ++i) F.pct[i] = c.percentiles[i];
-    F.roughness_bias = c.roughness_bias; F.irradiance_bias = c.irradiance_bias; F.ambient_bias = c.ambient_irradiance_bias;
-    F.rgb_max = c.rgb_max; F.slf_ambient_bias = c.slf_ambient_bias;
+    for (int l = 0; l < 3; ++l) F.jitter[l] = rnd ? rnd->jitter[l] : nullptr;
     F.out = A.out;
     F.direct = h->fused_direct;
     F.team = (h->fused_mode == 1 && !A.export_samples) ? 1 : 0;          // mode 3: the one-wavefront-per-ray form
@@ -1118,6 +1046,7 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     }
     // profiling: the single launch is reported as the "shader" stage, every other stage as 0
     for (int i = 0; i <= ST_SHADER; ++i) stage_mark(h, slot, i, st);
+    roctx_stage(F.team ? "k_cache_fused_team" : "k_cache_fused");
     rc_launch_fused(F, st);
     for (int i = ST_SHADER + 1; i <= ST_COUNT; ++i) stage_mark(h, slot, i, st);
     return;
@@ -1181,6 +1110,7 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     la.density_bias = c.density_bias; la.contract_radius = c.contract_radius; la.density = W(h, "density" + L);
     // (one ray per wave pays from ~100 rays per CU on: measured break-even of the whole pass near 32 k rays, +27 us at 1-4 k)
     if (level_kernel && (h->fused_mode == 1 || h->fused_mode == 3) && n >= 24576 && rc_level_ray_supported(h->grids[l].dev, S)) {
+      roctx_stage(l == 0 ? "level0 (sample+grid+mlp)" : (l == 1 ? "level1 (sample+grid+mlp)" : "level2 (sample+grid+mlp)"));
       rc_launch_level_ray(la, sa, st);
       continue;
     }
@@ -1322,6 +1252,7 @@ int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n, const rc_random
   if (n == 0) return RC_OK;
   if (!rays->origins || !rays->directions || !rays->viewdirs || !rays->near || !rays->far)
     return fail(h, RC_ERR_INVALID_ARG, "rc_render_rays: origins/directions/viewdirs/near/far are required");
+  RoctxScope roctx_call("rc_render_rays");
   if (h->transient) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_rays: this handle renders the time-resolved cache (rc_render_transient)");
   if (!(pass_mask & RC_PASS_CACHE)) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_rays: pass_mask must include RC_PASS_CACHE");
   const bool secondary = (pass_mask & RC_PASS_SECONDARY) != 0;
@@ -1482,6 +1413,7 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
                        const rc_mat_outputs* mat_out, void* stream_v) {
   RC_TRY
   if (!h) return RC_ERR_INVALID_ARG;
+  RoctxScope roctx_call("rc_render_material");
   if (h->transient) return fail(h, RC_ERR_UNSUPPORTED, "rc_render_material: this handle renders the time-resolved cache (rc_render_transient)");
   if (!rays || !mr || !cache_out || !mat_out) return fail(h, RC_ERR_INVALID_ARG, "rc_render_material: null argument");
   if (n < 0) return fail(h, RC_ERR_INVALID_ARG, "rc_render_material: negative n_rays");
@@ -1583,6 +1515,7 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
   // 3a. material head at the shading point (caller's stream) | 4. light sampler: 128 vMF lobes per shading point (side
   // stream) -- both read only the shading point; then 3b. the material head on all samples and the material-only
   // composite (side stream)
+  roctx_stage("material: heads + light sampler");
   {
     RcMatHeadArgs ma{};
     ma.w0 = raw("params/MaterialShader/bottleneck_layer", "kernel"); ma.b0 = raw("params/MaterialShader/bottleneck_layer", "bias");
@@ -1612,6 +1545,7 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     RC_HIP(h, hipStreamWaitEvent(st, h->ev_side[3], 0));          // the lobes
   }
   // 5. BRDF importance sampling -> secondary rays
+  roctx_stage("material: brdf sample");
   {
     RcBrdfSampleArgs sa{};
     sa.n = n; sa.Ks = Ks; sa.Kd = Kd; sa.Kc = Kc;
@@ -1659,6 +1593,7 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     side_join.forked = false;
   }
   // 7. Monte-Carlo BRDF integration + MaterialIntegrator composite
+  roctx_stage("material: integrate");
   {
     RcMatIntegrateArgs ia{};
     ia.n = n; ia.Ks = Ks; ia.Kd = Kd; ia.S = S2;

@@ -502,16 +502,8 @@ __global__ void k_build_cells(const float* __restrict__ src, int N, int F, float
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)M * M * M * 8;
   if (i >= total) return;
-  const int c = (int)(i & 7);
-  int64_t cell = i >> 3;
-  const int q0 = (int)(cell % M); cell /= M;
-  const int q1 = (int)(cell % M);
-  const int q2 = (int)(cell / M);
-  const int b0 = (c >> 2) & 1, b1 = (c >> 1) & 1, b2 = c & 1;
-  // cell origin q - 1 in padded coordinates; corners clamp to the padded volume [0, N + 1] (grid_utils.py:384-390)
-  const int k0 = min(max(q0 - 1 + b0, 0), N + 1), k1 = min(max(q1 - 1 + b1, 0), N + 1), k2 = min(max(q2 - 1 + b2, 0), N + 1);
-  const bool inside = (k0 >= 1) & (k0 <= N) & (k1 >= 1) & (k1 <= N) & (k2 >= 1) & (k2 <= N);
-  const int64_t e = ((int64_t)(k2 - 1) * N + (k1 - 1)) * N + (k0 - 1);
+  int64_t e;
+  const bool inside = rc_cell_corner(N, i, &e);      // rc_pack_host.h (the same rule runs under the CPU sanitizers)
   for (int f = 0; f < F; ++f) dst[i * dst_stride + dst_off + f] = inside ? src[e * F + f] : 0.0f;
 }
 

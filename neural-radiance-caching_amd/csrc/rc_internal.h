@@ -192,13 +192,7 @@ void rc_launch_envmap(const RcEnvMapArgs& a, hipStream_t stream);
 
 // IDE table layout (built on the host, see rc_api.hip): for deg_view 5 there are 36 (l,m)
 // terms; term i has polynomial coefficients in z of degree <= 16 and an xy power m.
-#define RC_IDE_TERMS 36
-#define RC_IDE_ZPOW 17
-struct RcIdeTable {
-  float coef[RC_IDE_TERMS][RC_IDE_ZPOW];
-  int32_t m[RC_IDE_TERMS];
-  float sigma[RC_IDE_TERMS];
-};
+#include "rc_pack_host.h"      // RC_IDE_TERMS, RC_IDE_ZPOW, RcIdeTable, rc_cell_corner (host-only header)
 
 // ---------------------------------------------------------------------------------------------
 // Material stage (rc_material.hip)
