@@ -344,11 +344,11 @@ __device__ __forceinline__ void ws_issue_rt(const WStream& w, int c, int nf) {
 // fragment J of column tile T of the stream.  T is a run-time value, J a constant once the callers' loops are
 // unrolled: a tile is exactly two chunks of the ring, so the seam test folds away and the waits / barriers sit at
 // J = 0 and J = kChunk of every tile
-__device__ __forceinline__ float ws_tile_frag(const WStream& w, int T, int J, int nf) {
+__device__ __forceinline__ float ws_tile_frag(const WStream& w, int T, int J, int nf, int c0) {
   static_assert(kFragsPerTile == 2 * kChunk, "tile = two chunks");
   if (J % kChunk == 0) {
     const int c = 2 * T + J / kChunk;
-    if (c > 0) {
+    if (c > c0) {         // c0: the first chunk of this launch's tile range (in flight since the prologue)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if ((c + 1) * kChunk < nf) ws_issue_rt(w, c + 1, nf);
@@ -361,14 +361,14 @@ __device__ __forceinline__ float ws_tile_frag(const WStream& w, int T, int J, in
 // (xi -> ai).  The two accumulator chains are interleaved 4 : 2 (a chain's next MFMA waits for its previous one; the
 // other chain fills the gap), and the host packs the tile's fragments in exactly this order:
 //   16 groups of [as 4g .. 4g+3 | ai 2g, 2g+1], then [as 64 | ai 32].
-__device__ __forceinline__ void tile_xw2(const WStream& w, int T, int nf, const float (&xs)[65], const float (&xi)[33],
+__device__ __forceinline__ void tile_xw2(const WStream& w, int T, int nf, int c0, const float (&xs)[65], const float (&xi)[33],
                                          f32x16& as, f32x16& ai) {
   constexpr int NG = 17;
   float b[3][6];                 // operands two groups ahead (three register sets, like mlp_layer)
   auto load = [&](int g, int buf) {
 #pragma unroll
     for (int q = 0; q < 6; ++q)
-      if (g < 16 || q < 2) b[buf][q] = ws_tile_frag(w, T, g * 6 + q, nf);
+      if (g < 16 || q < 2) b[buf][q] = ws_tile_frag(w, T, g * 6 + q, nf, c0);
   };
   load(0, 0);
   load(1, 1);
@@ -417,8 +417,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
   float* bsum = sp + kSP * 32;                     // [6][32] per-sample sums over bins (diffuse rgb, specular rgb)
   enum { P_W = 0, P_LDIST, P_CAMDIST, P_TIB0, P_TIB1, P_TIB2, P_DIND, P_KILL, P_LO, P_HI };
   WStream ws{a.wstream, ring, lane, wave};
-  ws_issue_rt(ws, 0, kBinFrags);
+  __shared__ int s_win[2 * kWaves];               // per ray of the workgroup: first / last bin any of its samples keeps
   for (int e = lane; e < 2 * kHistPad + kHist + 2 * kPadD; e += 64) wl[e] = 0.0f;
+  int win_lo = kBins, win_hi = -1;
   if (lane < 32) {
     const int64_t p = ray * 32 + lane;
     const float ld = a.tshade[RC_TS_LDIST * n + p];
@@ -450,7 +451,26 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
     if (kill) { lo = kBins; hi = -1; }
     sp[P_LO * 32 + lane] = __int_as_float(lo);
     sp[P_HI * 32 + lane] = __int_as_float(hi);
+    if (lo <= hi) { win_lo = lo; win_hi = hi; }
   }
+  // Column tiles outside [first, last] bin that ANY sample of the workgroup's rays keeps hold exact zeros on every lane
+  // (diff = spec = 0 there): their 98 MFMAs and their epilogue are not run, the weight stream starts at the first tile
+  // of the range.  The tile behind the range still runs: it places what the range's last three entries carry over.
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    win_lo = min(win_lo, __shfl_xor(win_lo, d, 64));
+    win_hi = max(win_hi, __shfl_xor(win_hi, d, 64));
+  }
+  if (lane == 0) { s_win[2 * wave] = win_lo; s_win[2 * wave + 1] = win_hi; }
+  __syncthreads();
+  int blo = kBins, bhi = -1;
+#pragma unroll
+  for (int q = 0; q < kWaves; ++q) { blo = min(blo, s_win[2 * q]); bhi = max(bhi, s_win[2 * q + 1]); }
+  // tile of entry f = 3 b + c is f / 32; groups of three tiles (T3) keep the channel phase of a lane a constant
+  const int T3_lo = blo <= bhi ? ((3 * blo) / 32) / 3 : 0;
+  const int T3_hi = blo <= bhi ? min(kTilesB / 3 - 1, ((3 * bhi + 2) / 32 + 1) / 3) : -1;
+  const int c0 = 2 * (3 * T3_lo);
+  if (T3_hi >= T3_lo) ws_issue_rt(ws, c0, kBinFrags);
   // activations of the two output layers (this ray's 32 samples), with the bias step
   float xs[65], xi[33];
 #pragma unroll
@@ -461,7 +481,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
   xi[32] = h == 0 ? 1.0f : 0.0f;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (kChunk < kBinFrags) ws_issue_rt(ws, 1, kBinFrags);
+  if (T3_hi >= T3_lo && (c0 + 1) * kChunk < kBinFrags) ws_issue_rt(ws, c0 + 1, kBinFrags);
 
   // per-sample sums over the bins: by tile phase u = T % 3 (the channel of a lane's entry is (2 u + fl) % 3)
   float sd[3][16], ss[3][16];
@@ -472,12 +492,13 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
 
   // Per-sample terms of this lane's 16 samples, kept in registers for all 66 tiles: weight, time shift, bin window
   float rw[16], rdm[16];
-  int rlo[16], rhi[16];
+  int rlo[16], rhi[16], rfl[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
     rw[r] = sp[P_W * 32 + i];
     rdm[r] = sp[P_DIND * 32 + i];
+    rfl[r] = (int)floorf(rdm[r]);
     rlo[r] = __float_as_int(sp[P_LO * 32 + i]);
     rhi[r] = __float_as_int(sp[P_HI * 32 + i]);
   }
@@ -501,7 +522,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
 #endif
       RC_BSTAMP(q0);
       f32x16 as = zero16(), ai = zero16();
-      tile_xw2(ws, T, kBinFrags, xs, xi, as, ai);
+      tile_xw2(ws, T, kBinFrags, c0, xs, xi, as, ai);
       RC_BSTAMP(q1);
       const int f = T * 32 + fl;                   // histogram entry of this lane
       const bool fok = f < kHist;
@@ -527,7 +548,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
         // below cover its latency.  The lanes of the first three entries take the neighbour's value from the tile
         // before (cval); a target outside the histogram goes to the lane's dummy slot.
         const float dmove = rdm[r];
-        const int y0 = b + (int)floorf(dmove);
+        const int y0 = b + rfl[r];
         const bool yok = y0 >= 0 && y0 < kBins;
         float* slot = hist_h + (yok ? y0 * 3 + c : kHist + fl);
 #if !(defined(RC_ABL) && RC_ABL == 2)
@@ -582,7 +603,16 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
 #endif
     }
   };
-  for (int T3 = 0; T3 < kTilesB / 3; ++T3) {
+  // the unshifted composites of the tiles that are not run: exact zeros
+  if (ray_ok && (a.out_ti_diffuse || a.out_ti_specular)) {
+    const int f_lo = 96 * T3_lo, f_hi = min(kHist, 96 * (T3_hi + 1));
+    for (int f = lane; f < kHist; f += 64) {
+      if (f >= f_lo && f < f_hi) continue;
+      if (a.out_ti_diffuse) a.out_ti_diffuse[ray * kHist + f] = 0.0f;
+      if (a.out_ti_specular) a.out_ti_specular[ray * kHist + f] = 0.0f;
+    }
+  }
+  for (int T3 = T3_lo; T3 <= T3_hi; ++T3) {
     tile_body(T3 * 3 + 0, 0, sd[0], ss[0]);
     tile_body(T3 * 3 + 1, 1, sd[1], ss[1]);
     tile_body(T3 * 3 + 2, 2, sd[2], ss[2]);

@@ -724,6 +724,29 @@ def test_transient_render_vs_fp64_golden(rc_transient, name):
     assert np.abs(out["acc"] - g["render_acc"]).max() <= RGB_TOL
 
 
+def test_transient_far_samples_run_only_their_tile_range(rc_transient):
+    """k_transient_bins runs the column tiles between the first and the last bin ANY sample of the workgroup's rays keeps
+    (zero_invalid_bins, render_utils.py:1699-1767) and writes exact zeros elsewhere.  Rays whose samples all lie 2.6-3.9
+    from camera and light keep bins ~[160, 440]: the range starts well inside the histogram on both sides."""
+    from oracle import transient_ref
+    n = 21
+    rays = nrc_amd.synthetic_transient_rays(n, seed=77, near=2.6, far=3.9)
+    cfg = nrc_amd.cornell_transient_config()
+    ref = transient_ref.transient_forward(common.to_torch(common.weights_transient_np()), cfg, common.rays_torch(rays), None, None)["render"]
+    ref = {k: v.numpy() for k, v in ref.items()}
+    out = rc_transient.render_transient(rays.hot_fields(), None)
+    torch.cuda.synchronize()
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    live = np.abs(ref["transient_indirect_diffuse"]).sum((0, 2)) > 0
+    assert live[:100].sum() == 0 and live[500:].sum() == 0 and live.sum() > 100          # the case is what it claims to be
+    for k in ("rgb", "transient_direct_viz", "transient_indirect_viz", "transient_indirect_diffuse", "transient_indirect_specular"):
+        assert np.abs(out[k] - ref[k]).max() <= 2e-5, k
+    for k in ("transient_indirect_diffuse", "transient_indirect_specular"):
+        assert not out[k][:, ~live].any(), k
+    for k in TRANSIENT_3:
+        assert np.abs(out[k] - ref[k]).max() <= RGB_TOL * max(1.0, np.abs(ref[k]).max()), k
+
+
 def test_transient_properties_full_batch_1024(rc_transient):
     """BASELINE-size batch: size-independent properties of the per-bin composite instead of an oracle run."""
     n = 1024
