@@ -115,6 +115,7 @@ struct rc_handle {
   int fused_mode = 1;
   RcFusedLaunch fused_tmpl{};      // launch descriptor of the fused plan, resolved at repack (build_fused_template)
   int fused_stagger = getenv("RC_FUSED_STAGGER") ? atoi(getenv("RC_FUSED_STAGGER")) : 0;   // experiment (rc_fused2.hip)
+  int fused_prio = getenv("RC_FUSED_PRIO") ? atoi(getenv("RC_FUSED_PRIO")) : 1;             // rc_fused2.hip: 1 = the younger workgroup of a CU leads through the lookups
 #ifdef RC_FUSED_DIRECT_EXPERIMENT
   int fused_direct = getenv("RC_FUSED_DIRECT") ? atoi(getenv("RC_FUSED_DIRECT")) : 0;   // experiment switch (see rc_fused.hip, DIRECT)
 #else
@@ -1038,6 +1039,7 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     F.direct = h->fused_direct;
     F.team = (h->fused_mode == 1 && !A.export_samples) ? 1 : 0;          // mode 3: the one-wavefront-per-ray form
     F.stagger_cycles = h->fused_stagger;
+    F.prio_mode = h->fused_prio;
     if (A.export_samples) {
       const std::string L2 = std::to_string(NL - 1);
       F.export_samples = 1;

@@ -51,23 +51,35 @@ __device__ __forceinline__ float wave_scan_incl(float v, int /*lane*/) {
 }
 // total of the wave in scan order (lane 63 of the inclusive scan), broadcast
 __device__ __forceinline__ float wave_sum_scan(float v) { return lane63(wave_scan_incl(v, 0)); }
+// Sum of a wave, broadcast to every lane: butterfly inside each row of 16 lanes on DPP moves (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror), the four row totals passed on with the two row broadcasts, lane 63 read back -- six
+// vector adds per value and no LDS crossbar (ds_bpermute) round trips.  wave_sum and wave_sum_n add in the same order.
+__device__ __forceinline__ float wave_sum_step(float v, int step) {
+  switch (step) {
+    case 0: return v + dpp_mov<0xB1>(0.0f, v);                 // quad_perm [1, 0, 3, 2]
+    case 1: return v + dpp_mov<0x4E>(0.0f, v);                 // quad_perm [2, 3, 0, 1]
+    case 2: return v + dpp_mov<0x141>(0.0f, v);                // row_half_mirror
+    case 3: return v + dpp_mov<0x140>(0.0f, v);                // row_mirror
+    case 4: return v + dpp_mov<0x142, 0xa, 0xf>(0.0f, v);      // row_bcast:15 into rows 1 and 3
+    default: return v + dpp_mov<0x143, 0xc, 0xf>(0.0f, v);     // row_bcast:31 into rows 2 and 3
+  }
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = v + __shfl_xor(v, d, 64);
-  return v;
+  for (int st = 0; st < 6; ++st) v = wave_sum_step(v, st);
+  return lane63(v);
 }
-// N independent wave sums at once: the N butterflies advance level by level, so the cross-lane
-// exchanges of one level are all in flight together (same add order per sum as wave_sum).
+// N independent wave sums at once: the N reductions advance step by step (independent adds back to back; same add
+// order per sum as wave_sum).
 template <int N>
 __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    float t[N];
+  for (int st = 0; st < 6; ++st) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) t[k] = __shfl_xor(v[k], d, 64);
-#pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = v[k] + t[k];
+    for (int k = 0; k < N; ++k) v[k] = wave_sum_step(v[k], st);
   }
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = lane63(v[k]);
 }
 __device__ __forceinline__ float wave_max(float v) {
   return lane63(wave_scan_op(v, -INFINITY, [](float a, float b) { return fmaxf(a, b); }));

@@ -579,6 +579,7 @@ void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream) {
 #endif
   if (L.team) {
     a.stagger_cycles = L.stagger_cycles;
+    a.prio_mode = L.prio_mode;
     rc_launch_fused_team(a, L.out.ptr[RC_OUT_NORMALS] != nullptr, stream);
     return;
   }

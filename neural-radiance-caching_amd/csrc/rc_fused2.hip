@@ -31,7 +31,10 @@ using namespace rcfused;
 namespace {
 
 constexpr int kTW = 4;                        // waves per workgroup: 2 rays x 2 waves
-constexpr int kTCH = 48;                      // fragments per ring chunk (12 KiB; the ring is 24 KiB)
+#ifndef RC_TCH
+#define RC_TCH 48
+#endif
+constexpr int kTCH = RC_TCH;                  // fragments per ring chunk (48: 12 KiB, the ring is 24 KiB)
 constexpr int kTRing = 2 * kTCH * 64;         // floats
 constexpr int kTScratch = 9 * 68;             // per ray: the 7 step-function arrays + density exchange + small hand-offs
 constexpr int kNF = NF_FUSED;
@@ -257,6 +260,15 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
       while (__builtin_amdgcn_s_memtime() - t_start < (unsigned long long)a.stagger_cycles) __builtin_amdgcn_s_sleep(16);
     }
   }
+  // Priorities.  The workgroup dispatched second onto a CU loses every issue arbitration to the older one (age): it
+  // falls 25 us behind in the proposal levels and then runs the tail of its shader alone, its stalls exposed.  Mode 1
+  // (default): the younger workgroup -- the second half of the grid, the dispatcher deals the first half one per CU --
+  // runs at s_setprio 1 up to its shader; the two then reach their matrix phases 20 us apart the other way round and
+  // end within 2 us of each other (129.9 -> 128.4 us per 1024-ray launch; 2 / 4: always the younger / the older, and
+  // 3: the younger in the shader only, measured 129.9 / 129.9 / 128.5).  Wrong guesses about who shares a CU cost nothing.
+  const bool young = blockIdx.x >= (gridDim.x >> 1);
+  if (young && (a.prio_mode == 1 || a.prio_mode == 2)) __builtin_amdgcn_s_setprio(1);
+  if (!young && a.prio_mode == 4) __builtin_amdgcn_s_setprio(1);
   RC_FSTAMP(0);
   ws_begin<kNF, kTW, kTCH>(ws);
 
@@ -475,6 +487,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
     }
   }
   RC_FSTAMP(9);
+  if (young && a.prio_mode == 1) __builtin_amdgcn_s_setprio(0);
+  if (young && a.prio_mode == 3) __builtin_amdgcn_s_setprio(1);
   // ------------------------------------------------------------------ shader on the 32 samples (rc_dev_mlp.h shader_tile)
   constexpr int F0 = F_SH;
   const float vx = a.viewdirs[3 * ray], vy = a.viewdirs[3 * ray + 1], vz = a.viewdirs[3 * ray + 2];

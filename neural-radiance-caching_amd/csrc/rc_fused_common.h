@@ -51,6 +51,7 @@ struct RcFusedArgs {
   rc_outputs out;
   unsigned long long* stamps;
   int32_t stagger_cycles;   // rc_fused2.hip: every second workgroup that arrives on a CU starts this many cycles late (0 = off)
+  int32_t prio_mode;        // rc_fused2.hip: wave priorities of the workgroup that arrived second on its CU (see the kernel)
   int32_t* cu_slots;        // rc_fused2.hip: arrival counters per physical CU (4096 entries, zero-initialised once)
   // FRONT variant (time-resolved cache): the proposal sampler only; what the launch-per-stage front end leaves in the
   // workspace for the stages behind it, in its layouts (np = n * 32 shaded samples)

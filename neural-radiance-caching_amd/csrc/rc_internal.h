@@ -268,6 +268,7 @@ struct RcFusedLaunch {
   int32_t direct;                      // weight fragments straight from global memory (no LDS ring, no workgroup barriers)
   int32_t team;                        // two wavefronts per ray, two workgroups per CU (rc_fused2.hip); plain pass only
   int32_t stagger_cycles;              // (team, experiment) late start of the second half of the grid
+  int32_t prio_mode;                   // (team) priority scheme of the younger workgroup of a CU
   int32_t use_raydist; float raydist_p, raydist_premult;
   float* f_tdist; float* f_density; float* f_means; float* f_normals_pred; float* f_normals_grad; float* f_hbuf; float* f_app;
 };

@@ -49,6 +49,22 @@ if os.environ.get("RC_FUSED_STAGGER", "0") not in ("", "0"):      # two-wavefron
               " ".join(f"{nm.split('+')[0][:9]} {np.median(seg[sel, i]) / ghz / 1e3:5.1f}" for i, nm in enumerate(names)) +
               f"; total {np.median(tot[sel]) / ghz / 1e3:6.1f} us; end {np.median(d[sel, 11] - t0.min()) / ghz / 1e3:6.1f} us")
 print("total median us", np.median(tot) / ghz / 1e3, "kernel span us", (d[:, 15].max() - d[:, 14].min()) / 100.0, "start skew us", (d[:, 14].max() - d[:, 14].min()) / 100.0)
+if os.environ.get("RC_STAMP_DETAIL"):
+    # who finishes last?  launch-relative start / end (100 MHz realtime counter) by workgroup (2 rays each) and XCD (block % 8)
+    rt_start = (d[:, 14] - d[:, 14].min()) / 100.0
+    rt_end = (d[:, 15] - d[:, 14].min()) / 100.0
+    blk = np.arange(n) // 2
+    print("end time us: min %.1f  p5 %.1f  median %.1f  p95 %.1f  max %.1f" % (rt_end.min(), np.percentile(rt_end, 5), np.median(rt_end), np.percentile(rt_end, 95), rt_end.max()))
+    for x in range(8):
+        sel = (blk % 8) == x
+        print(f"  block % 8 == {x}: start {np.median(rt_start[sel]):5.2f}  end median {np.median(rt_end[sel]):6.1f}  max {rt_end[sel].max():6.1f}  total(cyc)/ghz median {np.median(tot[sel]) / ghz / 1e3:6.1f}")
+    order = np.argsort(rt_end)
+    print("  10 last rays:", [(int(i), round(float(rt_end[i]), 1)) for i in order[-10:]])
+    half = blk >= (n // 4)
+    for nm2, sel in (("first half", ~half), ("second half", half)):
+        print(f"  [{nm2}] " + " ".join(f"{nm.split('+')[0][:9]} {np.median(seg[sel, i]) / ghz / 1e3:5.1f}" for i, nm in enumerate(names)) +
+              f"; shader start {np.median((d[sel, 9] - d[sel, 0])) / ghz / 1e3:6.1f} end {np.median((d[sel, 10] - d[sel, 0])) / ghz / 1e3:6.1f} us after its own start")
+    print("  first half of the grid: end median %.1f max %.1f; second half: end median %.1f max %.1f" % (np.median(rt_end[~half]), rt_end[~half].max(), np.median(rt_end[half]), rt_end[half].max()))
 if len(sys.argv) > 3:      # JSON for profiles/fused_phase_stamps.json (bench.py's hashgrid.in_fused_kernel block)
     import json
     json.dump({"source_hash": rc_ext.source_hash(), "n_rays": n, "rays": mode, "clock_ghz": float(ghz),
