@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 2
+#define RC_ABI_VERSION 3
 #define RC_MAX_LEVELS 3
 
 typedef struct rc_handle rc_handle;
@@ -363,8 +363,10 @@ int rc_render_transient(rc_handle* h, const rc_rays* rays, const float* cam_orig
 
 /* ------------------------------------------------------------------------------------------------
  * On-device ray generation: camera_utils.pixels_to_rays + cast_ray_batch
- * (internal/camera_utils.py:896-1072, 1225-1329) for one pinhole camera (ProjectionType.PERSPECTIVE,
- * no distortion / NDC / z_range / pixel jitter).  The outputs are the device arrays rc_rays points to.
+ * (internal/camera_utils.py:896-1072, 1225-1329) for one camera: ProjectionType.PERSPECTIVE / FISHEYE /
+ * FISHEYE_EQUISOLID / PANORAMIC, optional radial + tangential distortion (:795-890, Newton undistortion, 10 steps),
+ * optional NDC (convert_to_ndc, :50-111; radii then from the offsets between NDC origins, :1058-1066).  No z_range,
+ * no pixel jitter.  The outputs are the device arrays rc_rays points to.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct rc_camera {
   float pixtocam[9];     /* inverse intrinsics, row-major [3,3] (camera_utils.get_pixtocam)              */
@@ -372,7 +374,13 @@ typedef struct rc_camera {
   float light[3];        /* lights[cam_idx] (camera_utils.py:1288)                                       */
   float near, far;       /* Pixels.near / Pixels.far                                                     */
   int32_t camtype;       /* 0 ProjectionType.PERSPECTIVE, 1 PANORAMIC (cast_spherical_rays, camera_utils.py:1415-1443,
-                          * 1013-1024: pixtocam = diag(2 pi / W, pi / H, 1), (theta, phi) -> direction)           */
+                          * 1013-1024: pixtocam = diag(2 pi / W, pi / H, 1), (theta, phi) -> direction),
+                          * 2 FISHEYE (equidistant, theta = min(pi, r)), 3 FISHEYE_EQUISOLID (theta = 2 asin(r / 2)) (:991-1011) */
+  /* -- ABI v3 -- */
+  int32_t has_distortion;   /* distortion_params is not None (:981-989)                                  */
+  float distortion[6];      /* k1, k2, k3, k4, p1, p2                                                    */
+  int32_t has_ndc;          /* pixtocam_ndc is not None (:1052-1066)                                     */
+  float pixtocam_ndc[9];    /* inverse intrinsics of the NDC projection, row-major [3,3]                 */
 } rc_camera;
 typedef struct rc_cast_outputs {
   float* origins; float* directions; float* viewdirs;   /* [n,3] */

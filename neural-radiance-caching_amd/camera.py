@@ -4,7 +4,8 @@
     get_pixtocam(focal, width, height)           camera_utils.get_pixtocam     internal/camera_utils.py:760-763
     render_camera(model, camera, height, width)  trainer.render_primary_rays   engine/trainer.py:812-846 (pose in, image out)
 
-Only what the BASELINE scenes use: ProjectionType.PERSPECTIVE, no distortion / NDC / z_range / pixel jitter.
+ProjectionType.PERSPECTIVE (the BASELINE scenes), PANORAMIC, FISHEYE, FISHEYE_EQUISOLID; optional radial + tangential
+distortion and NDC rays (camera_utils.py:795-890, 50-111); no z_range, no pixel jitter.
 The returned Rays hold torch cuda tensors (nothing crosses PCIe but the 3x3 + 3x4 matrices).
 """
 from __future__ import annotations
@@ -31,7 +32,9 @@ class Camera:
     light: Optional[np.ndarray] = None   # [3]; default: the camera centre (datasets.py:1348)
     near: float = 2.0
     far: float = 6.0
-    camtype: str = "perspective"       # ProjectionType value: "perspective" or "pano"
+    camtype: str = "perspective"       # ProjectionType value: "perspective", "pano", "fisheye" or "fisheye_equisolid"
+    distortion_params: Optional[dict] = None   # {"k1", "k2", "k3", "k4", "p1", "p2"} (camera_utils.py:981-989)
+    pixtocam_ndc: Optional[np.ndarray] = None  # [3, 3]: rays in NDC space (camera_utils.py:1052-1066)
 
 
 def cast_spherical_rays(rc, camtoworld, height: int, width: int, near: float, far: float, light=None) -> Rays:

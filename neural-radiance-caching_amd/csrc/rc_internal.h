@@ -338,7 +338,9 @@ struct RcCastArgs {
   int32_t x0, y0, width;
   float pixtocam[9]; float rot[9]; float trans[3]; float light[3];
   float near_v, far_v;
-  int32_t camtype;                                  // 0 perspective, 1 panoramic
+  int32_t camtype;                                  // 0 perspective, 1 panoramic, 2 fisheye, 3 fisheye (equisolid)
+  int32_t has_distortion; float dist[6];            // k1 k2 k3 k4 p1 p2
+  int32_t has_ndc; float ndc_xmult, ndc_ymult;      // 1 / pixtocam_ndc[0][2], 1 / pixtocam_ndc[1][2]
   float* origins; float* directions; float* viewdirs; float* radii; float* imageplane; float* look; float* up;
   float* lights; float* near; float* far;
 };

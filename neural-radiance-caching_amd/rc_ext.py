@@ -14,7 +14,7 @@ import numpy as np
 
 from .config import GridConfig, RenderConfig
 
-RC_ABI_VERSION = 2
+RC_ABI_VERSION = 3
 RC_MAX_LEVELS = 3
 
 RC_PASS_CACHE = 0x1
@@ -132,7 +132,9 @@ class rc_transient_outputs(C.Structure):
 
 class rc_camera(C.Structure):
     _fields_ = [("pixtocam", C.c_float * 9), ("camtoworld", C.c_float * 12), ("light", C.c_float * 3),
-                ("near", C.c_float), ("far", C.c_float), ("camtype", C.c_int32)]
+                ("near", C.c_float), ("far", C.c_float), ("camtype", C.c_int32),
+                ("has_distortion", C.c_int32), ("distortion", C.c_float * 6),
+                ("has_ndc", C.c_int32), ("pixtocam_ndc", C.c_float * 9)]
 
 
 CAST_OUTPUTS = (("origins", 3), ("directions", 3), ("viewdirs", 3), ("radii", 1), ("imageplane", 2), ("look", 3), ("up", 3),
@@ -601,7 +603,8 @@ class RadianceCache:
         return out
 
     def cast_rays(self, camera, pix_x_int=None, pix_y_int=None, rect=None):
-        """rc_cast_rays: pinhole rays of `camera` (pixtocam [3,3], camtoworld [3,4], light, near, far) for an explicit
+        """rc_cast_rays: rays of `camera` (pixtocam [3,3], camtoworld [3,4], light, near, far; optional camtype,
+        distortion_params, pixtocam_ndc as in camera_utils.pixels_to_rays) for an explicit
         pixel batch (two int arrays of one shape) or for rect = (x0, y0, width, height), as a Rays of cuda tensors
         with the batch shape of the pixels ([h, w, .] for a rectangle)."""
         from .rays import Rays
@@ -617,7 +620,17 @@ class RadianceCache:
         for i in range(3):
             cam.light[i] = float(light[i])
         cam.near, cam.far = float(camera.near), float(camera.far)
-        cam.camtype = {"perspective": 0, "pano": 1}[getattr(camera, "camtype", "perspective")]
+        cam.camtype = {"perspective": 0, "pano": 1, "fisheye": 2, "fisheye_equisolid": 3}[getattr(camera, "camtype", "perspective")]
+        dist = getattr(camera, "distortion_params", None)
+        if dist is not None:              # dict of floats like the reference's distortion_params (k1..k4, p1, p2; missing = 0)
+            cam.has_distortion = 1
+            for i, k in enumerate(("k1", "k2", "k3", "k4", "p1", "p2")):
+                cam.distortion[i] = float(dist.get(k, 0.0))
+        ndc = getattr(camera, "pixtocam_ndc", None)
+        if ndc is not None:
+            cam.has_ndc = 1
+            for i, v in enumerate(np.asarray(ndc, np.float32).reshape(9)):
+                cam.pixtocam_ndc[i] = float(v)
         dev = f"cuda:{self.device}"
         if rect is not None:
             x0, y0, w, hgt = (int(v) for v in rect)

@@ -1,8 +1,9 @@
 """Pinhole ray generation (oracle; see oracle/__init__.py -- PARITY UNPINNED like the rest).
 
-Restates camera_utils.pixels_to_rays (internal/camera_utils.py:896-1072) and the parts of cast_ray_batch
-(:1225-1329) that apply to the BASELINE scenes: ProjectionType.PERSPECTIVE, distortion_params=None,
-pixtocam_ndc=None, z_range=None, jitter=0, xnp=numpy (the dataset / eval path casts with numpy).
+Restates camera_utils.pixels_to_rays (internal/camera_utils.py:896-1072) and cast_ray_batch (:1225-1329):
+ProjectionType.PERSPECTIVE (the BASELINE scenes), PANORAMIC, FISHEYE, FISHEYE_EQUISOLID, distortion_params
+(_radial_and_tangential_undistort, :795-890), pixtocam_ndc (convert_to_ndc, :50-111); z_range=None, jitter=0,
+xnp=numpy (the dataset / eval path casts with numpy).
 """
 from __future__ import annotations
 
@@ -15,7 +16,55 @@ def get_pixtocam(focal, width, height):
     return np.linalg.inv(camtopix)
 
 
-def pixels_to_rays(pix_x_int, pix_y_int, pixtocam, camtoworld, dtype=np.float32, camtype="perspective"):
+def _residual_and_jacobian(x, y, xd, yd, k1, k2, k3, k4, p1, p2):
+    """camera_utils._compute_residual_and_jacobian (:795-841)."""
+    r = x * x + y * y
+    d = 1.0 + r * (k1 + r * (k2 + r * (k3 + r * k4)))
+    fx = d * x + 2 * p1 * x * y + p2 * (r + 2 * x * x) - xd
+    fy = d * y + 2 * p2 * x * y + p1 * (r + 2 * y * y) - yd
+    d_r = k1 + r * (2.0 * k2 + r * (3.0 * k3 + r * 4.0 * k4))
+    d_x = 2.0 * x * d_r
+    d_y = 2.0 * y * d_r
+    fx_x = d + d_x * x + 2.0 * p1 * y + 6.0 * p2 * x
+    fx_y = d_y * x + 2.0 * p1 * x + 2.0 * p2 * y
+    fy_x = d_x * y + 2.0 * p2 * y + 2.0 * p1 * x
+    fy_y = d + d_y * y + 2.0 * p2 * x + 6.0 * p1 * y
+    return fx, fy, fx_x, fx_y, fy_x, fy_y
+
+
+def radial_and_tangential_undistort(xd, yd, k1=0, k2=0, k3=0, k4=0, p1=0, p2=0, eps=1e-9, max_iterations=10):
+    """camera_utils._radial_and_tangential_undistort (:844-890): Newton steps from the distorted point.  The
+    coefficients take the dtype of the coordinates (the C ABI carries them as float32)."""
+    dt = np.asarray(xd).dtype.type
+    k1, k2, k3, k4, p1, p2 = (dt(v) for v in (k1, k2, k3, k4, p1, p2))
+    x, y = np.copy(xd), np.copy(yd)
+    for _ in range(max_iterations):
+        fx, fy, fx_x, fx_y, fy_x, fy_y = _residual_and_jacobian(x, y, xd, yd, k1, k2, k3, k4, p1, p2)
+        denominator = fy_x * fx_y - fx_x * fy_y
+        x_numerator = fx * fy_y - fy * fx_y
+        y_numerator = fy * fx_x - fx * fy_x
+        ok = np.abs(denominator) > eps
+        safe = np.where(ok, denominator, np.ones_like(denominator))
+        x = x + np.where(ok, x_numerator / safe, np.zeros_like(denominator))
+        y = y + np.where(ok, y_numerator / safe, np.zeros_like(denominator))
+    return x, y
+
+
+def convert_to_ndc(origins, directions, pixtocam, near=1.0):
+    """camera_utils.convert_to_ndc (:50-111)."""
+    t = -(near + origins[..., 2]) / directions[..., 2]
+    origins = origins + t[..., None] * directions
+    dx, dy, dz = np.moveaxis(directions, -1, 0)
+    ox, oy, oz = np.moveaxis(origins, -1, 0)
+    xmult = 1.0 / pixtocam[0, 2]
+    ymult = 1.0 / pixtocam[1, 2]
+    origins_ndc = np.stack([xmult * ox / oz, ymult * oy / oz, -np.ones_like(oz)], axis=-1)
+    infinity_ndc = np.stack([xmult * dx / dz, ymult * dy / dz, np.ones_like(oz)], axis=-1)
+    return origins_ndc, infinity_ndc - origins_ndc
+
+
+def pixels_to_rays(pix_x_int, pix_y_int, pixtocam, camtoworld, dtype=np.float32, camtype="perspective",
+                   distortion_params=None, pixtocam_ndc=None):
     pix_x_int = np.asarray(pix_x_int)
     pix_y_int = np.asarray(pix_y_int)
     pixtocam = np.asarray(pixtocam, dtype)
@@ -29,7 +78,15 @@ def pixels_to_rays(pix_x_int, pix_y_int, pixtocam, camtoworld, dtype=np.float32,
     stacked = np.stack([pix_to_dir(px, py), pix_to_dir(px + 1, py), pix_to_dir(px, py + 1)], axis=0)
     mat_vec_mul = lambda A, b: np.matmul(A, b[..., None])[..., 0]
     cam_dirs = mat_vec_mul(pixtocam, stacked)
-    if camtype == "pano":
+    if distortion_params is not None:
+        x, y = radial_and_tangential_undistort(cam_dirs[..., 0], cam_dirs[..., 1], **distortion_params)
+        cam_dirs = np.stack([x, y, np.ones_like(x)], -1)
+    if camtype in ("fisheye", "fisheye_equisolid"):
+        r = np.sqrt(np.sum(np.square(cam_dirs[..., :2]), axis=-1))
+        theta = np.minimum(np.pi, r).astype(dtype) if camtype == "fisheye" else 2.0 * np.arcsin(r / 2.0)
+        s_over_r = np.sin(theta) / r
+        cam_dirs = np.stack([cam_dirs[..., 0] * s_over_r, cam_dirs[..., 1] * s_over_r, np.cos(theta)], axis=-1).astype(dtype)
+    elif camtype == "pano":
         # ProjectionType.PANORAMIC (:1013-1024)
         theta, phi = cam_dirs[..., 0], cam_dirs[..., 1]
         cam_dirs = np.stack([-np.sin(phi) * np.sin(theta), -np.cos(phi), -np.sin(phi) * np.cos(theta)], axis=-1).astype(dtype)
@@ -41,16 +98,25 @@ def pixels_to_rays(pix_x_int, pix_y_int, pixtocam, camtoworld, dtype=np.float32,
     viewdirs = directions / np.linalg.norm(directions, axis=-1, keepdims=True)
     look = np.broadcast_to(-camtoworld[..., :3, 2], directions.shape)
     up = np.broadcast_to(camtoworld[..., :3, 1], directions.shape)
-    dx_norm = np.linalg.norm(dx - directions, axis=-1)
-    dy_norm = np.linalg.norm(dy - directions, axis=-1)
+    if pixtocam_ndc is None:
+        dx_norm = np.linalg.norm(dx - directions, axis=-1)
+        dy_norm = np.linalg.norm(dy - directions, axis=-1)
+    else:
+        p_ndc = np.asarray(pixtocam_ndc, dtype)
+        origins_dx, _ = convert_to_ndc(origins, dx, p_ndc)
+        origins_dy, _ = convert_to_ndc(origins, dy, p_ndc)
+        origins, directions = convert_to_ndc(origins, directions, p_ndc)
+        dx_norm = np.linalg.norm(origins_dx - origins, axis=-1)
+        dy_norm = np.linalg.norm(origins_dy - origins, axis=-1)
     radii = (0.5 * (dx_norm + dy_norm))[..., None] * 2 / np.sqrt(12)
     return dict(origins=origins, directions=directions, viewdirs=viewdirs, radii=radii.astype(dtype), imageplane=imageplane,
                 look=look, up=up)
 
 
-def cast_ray_batch(pixtocam, camtoworld, light, pix_x_int, pix_y_int, near, far, dtype=np.float32, camtype="perspective"):
+def cast_ray_batch(pixtocam, camtoworld, light, pix_x_int, pix_y_int, near, far, dtype=np.float32, camtype="perspective",
+                   distortion_params=None, pixtocam_ndc=None):
     """cast_ray_batch for one camera: rays + lights = lights[cam_idx], cam_origins = origins, near / far from Pixels."""
-    r = pixels_to_rays(pix_x_int, pix_y_int, pixtocam, camtoworld, dtype, camtype)
+    r = pixels_to_rays(pix_x_int, pix_y_int, pixtocam, camtoworld, dtype, camtype, distortion_params, pixtocam_ndc)
     shape = r["directions"].shape
     r["lights"] = np.broadcast_to(np.asarray(light, dtype), shape)
     r["cam_origins"] = r["origins"]

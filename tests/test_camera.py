@@ -128,4 +128,81 @@ def test_spherical_rays_on_device_match_oracle():
         assert g.shape == ref[k].shape, k
         assert np.abs(g - ref[k]).max() <= 4e-6 * max(1.0, np.abs(ref[k]).max()), k
     with pytest.raises(KeyError):
-        rc.cast_rays(nrc_amd.Camera(np.eye(3), c2w, camtype="fisheye"), rect=(0, 0, 2, 2))
+        rc.cast_rays(nrc_amd.Camera(np.eye(3), c2w, camtype="orthographic"), rect=(0, 0, 2, 2))
+
+
+# ---- the rest of pixels_to_rays: distortion, fisheye, NDC (camera_utils.py:795-890, 991-1011, 50-111, 1052-1066)
+DIST = dict(k1=0.08, k2=-0.03, k3=0.004, k4=0.0, p1=0.002, p2=-0.0015)
+
+
+def test_undistortion_inverts_the_distortion_model():
+    """The forward model (:808-816): xd = x d + 2 p1 x y + p2 (r + 2 x^2), yd likewise; the Newton undistortion takes
+    the distorted point back."""
+    rng = np.random.default_rng(3)
+    x, y = rng.uniform(-0.6, 0.6, size=(2, 200))
+    k1, k2, k3, k4, p1, p2 = (DIST[k] for k in ("k1", "k2", "k3", "k4", "p1", "p2"))
+    r = x * x + y * y
+    d = 1 + r * (k1 + r * (k2 + r * (k3 + r * k4)))
+    xd = x * d + 2 * p1 * x * y + p2 * (r + 2 * x * x)
+    yd = y * d + 2 * p2 * x * y + p1 * (r + 2 * y * y)
+    ux, uy = camera_ref.radial_and_tangential_undistort(xd, yd, **DIST)
+    assert np.abs(ux - x).max() <= 1e-12 and np.abs(uy - y).max() <= 1e-12
+    # no distortion: the identity, whatever the iteration count
+    ux, uy = camera_ref.radial_and_tangential_undistort(xd, yd)
+    assert np.array_equal(ux, xd) and np.array_equal(uy, yd)
+
+
+def test_fisheye_and_ndc_known_answers():
+    H, W, f = 8, 10, 7.0          # even sizes: no pixel centre on the optical axis (sin(theta) / r is 0 / 0 there, as in the reference)
+    p2c = camera_ref.get_pixtocam(f, W, H)
+    c2w = np.concatenate([np.eye(3), np.zeros((3, 1))], axis=1)
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H), indexing="xy")
+    # equidistant fisheye: the angle between a ray and the optical axis (-z after the OpenGL flip) is the image-plane
+    # radius over the focal length; equisolid: r = 2 sin(theta / 2)
+    rad = np.hypot((xs + 0.5 - W / 2) / f, (ys + 0.5 - H / 2) / f)
+    for camtype, theta in (("fisheye", np.minimum(np.pi, rad)), ("fisheye_equisolid", 2 * np.arcsin(rad / 2))):
+        r = camera_ref.pixels_to_rays(xs, ys, p2c, c2w, np.float64, camtype=camtype)
+        assert np.allclose(np.linalg.norm(r["directions"], axis=-1), 1.0)
+        assert np.allclose(np.arccos(-r["directions"][..., 2]), theta, atol=1e-12), camtype
+    # NDC (NeRF appendix C): origins land on the near plane z = -1, directions have z = 2, and
+    # origin + direction = the projection of the point at infinity (xmult dx / dz, ymult dy / dz, 1)
+    c2w = _lookat([0.2, -0.1, 3.0])
+    c2w[:, :3] = np.eye(3)                                           # forward facing: the camera looks down -z
+    r = camera_ref.pixels_to_rays(xs, ys, p2c, c2w, np.float64, pixtocam_ndc=p2c)
+    plain = camera_ref.pixels_to_rays(xs, ys, p2c, c2w, np.float64)
+    assert np.allclose(r["origins"][..., 2], -1.0) and np.allclose(r["directions"][..., 2], 2.0)
+    d = plain["directions"]
+    inf = np.stack([d[..., 0] / d[..., 2] / p2c[0, 2], d[..., 1] / d[..., 2] / p2c[1, 2], np.ones_like(d[..., 2])], -1)
+    assert np.allclose(r["origins"] + r["directions"], inf)
+    assert np.array_equal(r["viewdirs"], plain["viewdirs"])           # viewdirs are taken before the conversion
+    assert np.all(r["radii"] > 0) and r["radii"].shape == (H, W, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["distortion", "fisheye", "fisheye_equisolid", "ndc", "distortion+ndc"])
+def test_cast_rays_distortion_fisheye_ndc_on_device(case):
+    from nrc_amd import rc_ext
+    rc = rc_ext.RadianceCache(nrc_amd.hotdog_config(), 0)
+    H, W, f = 30, 44, 40.0
+    p2c = nrc_amd.get_pixtocam(f, W, H)
+    c2w = _lookat([2.0, -3.0, 1.5])
+    kw = {}
+    if "fisheye" in case:
+        kw["camtype"] = case
+    if "distortion" in case:
+        kw["distortion_params"] = DIST
+    if "ndc" in case:
+        c2w = np.concatenate([np.eye(3), [[0.2], [-0.1], [3.0]]], axis=1)
+        kw["pixtocam_ndc"] = p2c
+    cam = nrc_amd.Camera(p2c, c2w, light=[2.1, -3.0, 1.6], near=0.0, far=1.0, **kw)
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H), indexing="xy")
+    ref = camera_ref.cast_ray_batch(cam.pixtocam, cam.camtoworld, cam.light, xs, ys, 0.0, 1.0, camtype=kw.get("camtype", "perspective"),
+                                    distortion_params=kw.get("distortion_params"), pixtocam_ndc=kw.get("pixtocam_ndc"))
+    got = rc.cast_rays(cam, rect=(0, 0, W, H))
+    torch.cuda.synchronize()
+    for k in ("origins", "directions", "viewdirs", "radii", "imageplane", "look", "up", "lights", "near", "far"):
+        g = getattr(got, k).cpu().numpy()
+        assert g.shape == ref[k].shape, k
+        # 2e-6 like the pinhole test; the radii of the NDC rays are differences of two NDC origins ~1 apart (cancellation)
+        tol = 2e-5 if ("ndc" in case and k == "radii") else 4e-6
+        assert np.abs(g - ref[k]).max() <= tol * max(1.0, np.abs(ref[k]).max()), (k, np.abs(g - ref[k]).max())

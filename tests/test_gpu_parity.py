@@ -204,6 +204,29 @@ def test_fused_plan_equals_staged_plan(rc, n, jitter_seed):
     _staged_matches(rc, out, n, jitter_seed, tol=FUSED_TOL)
 
 
+@pytest.mark.parametrize("n,jitter_seed", [(1, None), (2, 3), (3, None), (64, 5), (1023, None), (4097, 8)])
+def test_two_wave_fused_kernel_equals_the_one_wave_kernel(rc, n, jitter_seed):
+    """rc_set_fused 1 (k_cache_fused_team: two wavefronts per ray, two rays per workgroup, csrc/rc_fused2.hip) against
+    rc_set_fused 3 (k_cache_fused: one wavefront per ray): the same weight stream, the same MFMA order per accumulator,
+    the same scans -- every output bitwise equal, odd ray counts (a workgroup with one live ray) included; with and
+    without requesting the analytic normals (the GRAD / non-GRAD instantiations)."""
+    rays = nrc_amd.synthetic_rays(n, seed=900 + n)
+    rnd = None if jitter_seed is None else {"jitter": common.jitters(n, seed=jitter_seed)}
+    for outputs in (None, ["rgb", "acc", "distance_median", "normals_pred"]):
+        res = {}
+        for mode in (1, 3):
+            rc.set_fused(mode)
+            try:
+                out = rc.render_rays(rays.hot_fields(), rnd, **({} if outputs is None else {"outputs": outputs}))
+                torch.cuda.synchronize()
+            finally:
+                rc.set_fused(True)
+            res[mode] = {k: v.clone() for k, v in out.items()}
+        for k in res[1]:
+            assert torch.equal(res[1][k], res[3][k]), (k, outputs)
+            assert bool(torch.isfinite(res[1][k]).all()), k
+
+
 def test_empty_batch_is_a_noop(rc):
     rays = nrc_amd.synthetic_rays(4)
     f = {k: np.asarray(v)[:0] for k, v in rays.hot_fields().items()}
