@@ -220,7 +220,11 @@ template <bool GRAD>
 __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int rs = wave & 1, q = wave >> 1;            // ray slot of the workgroup, role half of the ray
+  // ray slot of the workgroup, role half of the ray.  Wave 0 of a ray carries the single-wave phases (scans, heads,
+  // compositing): prio_mode bit 3 (experiment) swaps the roles in the second half of the grid, so that a SIMD shared by
+  // two workgroups does not host two such waves (waves go to SIMDs by their index)
+  const int rs = wave & 1;
+  const int q = (wave >> 1) ^ (((a.prio_mode & 8) && blockIdx.x >= (gridDim.x >> 1)) ? 1 : 0);
   int64_t ray = (int64_t)blockIdx.x * 2 + rs;
   const bool ray_ok = ray < a.n;
   if (!ray_ok) ray = a.n - 1;                        // keep the wave in the workgroup's lockstep
@@ -267,8 +271,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
   // end within 2 us of each other (129.9 -> 128.4 us per 1024-ray launch; 2 / 4: always the younger / the older, and
   // 3: the younger in the shader only, measured 129.9 / 129.9 / 128.5).  Wrong guesses about who shares a CU cost nothing.
   const bool young = blockIdx.x >= (gridDim.x >> 1);
-  if (young && (a.prio_mode == 1 || a.prio_mode == 2)) __builtin_amdgcn_s_setprio(1);
-  if (!young && a.prio_mode == 4) __builtin_amdgcn_s_setprio(1);
+  const int pm = a.prio_mode & 7;
+  if (young && (pm == 1 || pm == 2)) __builtin_amdgcn_s_setprio(1);
+  if (!young && pm == 4) __builtin_amdgcn_s_setprio(1);
   RC_FSTAMP(0);
   ws_begin<kNF, kTW, kTCH>(ws);
 
@@ -487,8 +492,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
     }
   }
   RC_FSTAMP(9);
-  if (young && a.prio_mode == 1) __builtin_amdgcn_s_setprio(0);
-  if (young && a.prio_mode == 3) __builtin_amdgcn_s_setprio(1);
+  if (young && pm == 1) __builtin_amdgcn_s_setprio(0);
+  if (young && pm == 3) __builtin_amdgcn_s_setprio(1);
   // ------------------------------------------------------------------ shader on the 32 samples (rc_dev_mlp.h shader_tile)
   constexpr int F0 = F_SH;
   const float vx = a.viewdirs[3 * ray], vy = a.viewdirs[3 * ray + 1], vz = a.viewdirs[3 * ray + 2];
@@ -707,7 +712,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
     unsigned long long* d = a.stamps + ray * 16;
     for (int i = 0; i < 12; ++i) d[i] = stamps[i];
     d[14] = rt0; d[15] = __builtin_amdgcn_s_memrealtime();
-    d[12] = 0; d[13] = 0;
+    d[12] = (unsigned long long)blockIdx.x; d[13] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
   }
 #endif
 }

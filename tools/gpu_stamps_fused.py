@@ -61,6 +61,12 @@ if os.environ.get("RC_STAMP_DETAIL"):
     order = np.argsort(rt_end)
     print("  10 last rays:", [(int(i), round(float(rt_end[i]), 1)) for i in order[-10:]])
     half = blk >= (n // 4)
+    hw = d[:, 13].astype(np.int64)
+    if hw.any():       # HW_REG_HW_ID of wave 0 of each ray: SIMD_ID bits 5:4, CU_ID 11:8, SH_ID 12, SE_ID 15:13
+        simd = (hw >> 4) & 3
+        cu = (hw >> 8) & 0xff
+        print("  SIMD of the stamping wave: first half", np.bincount(simd[~half], minlength=4), "second half", np.bincount(simd[half], minlength=4),
+              "; even ray slots", np.bincount(simd[0::2], minlength=4), "odd", np.bincount(simd[1::2], minlength=4))
     for nm2, sel in (("first half", ~half), ("second half", half)):
         print(f"  [{nm2}] " + " ".join(f"{nm.split('+')[0][:9]} {np.median(seg[sel, i]) / ghz / 1e3:5.1f}" for i, nm in enumerate(names)) +
               f"; shader start {np.median((d[sel, 9] - d[sel, 0])) / ghz / 1e3:6.1f} end {np.median((d[sel, 10] - d[sel, 0])) / ghz / 1e3:6.1f} us after its own start")

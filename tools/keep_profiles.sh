@@ -9,6 +9,7 @@ cp $O/fused_phase_stamps.txt profiles/${R}_fused_phase_stamps.txt
 for m in tile strip; do cp $O/fused_phase_stamps_$m.json profiles/fused_phase_stamps_$m.json; cp $O/fused_phase_stamps_$m.txt profiles/${R}_fused_phase_stamps_$m.txt; done
 cp $O/fused/fused_kernel_stats.csv profiles/${R}_kernel_stats.csv
 cp $O/staged/staged_kernel_stats.csv profiles/${R}_kernel_stats_staged_plan.csv
+cp $O/fused1/fused1_kernel_stats.csv profiles/${R}_kernel_stats_one_wave_per_ray.csv
 cp $O/material/material_kernel_stats.csv profiles/${R}_material_kernel_stats.csv
 cp $O/material_pmc_counters.txt profiles/${R}_material_pmc_counters.txt
 python tools/prof_summary.py $O > profiles/${R}_summary.txt

@@ -13,6 +13,8 @@ B="python $ROOT/bench.py --no-cpu-baseline --no-material --no-train --no-image"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fused -o fused -- $B > $O/bench_fused.json 2> $O/fused.err
 echo "fused trace done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/fused1 -o fused1 -- $B --no-transient --plan fused1 > $O/bench_fused1.json 2> $O/fused1.err
+echo "fused1 (one wavefront per ray) trace done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/staged -o staged -- $B --no-transient --plan staged > $O/bench_staged.json 2> $O/staged.err
 echo "staged trace done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/material -o material -- python $ROOT/tools/bench_material.py > $O/bench_material.txt 2> $O/material.err

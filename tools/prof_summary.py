@@ -29,6 +29,8 @@ p = os.path.join(O, "pmc_k_cache_fused.json")
 if os.path.exists(p):
     print("# kernel sources:", json.load(open(p))["source_hash"])
 stats(os.path.join(O, "fused", "fused_kernel_stats.csv"), "kernel trace, fused plan (default bench; includes the transient line's kernels and the staged separate pass)")
+if os.path.exists(os.path.join(O, "fused1", "fused1_kernel_stats.csv")):
+    stats(os.path.join(O, "fused1", "fused1_kernel_stats.csv"), "kernel trace, fused plan with ONE wavefront per ray (--plan fused1; rc_set_fused 3: the round-1/2 kernel)", 6)
 stats(os.path.join(O, "staged", "staged_kernel_stats.csv"), "kernel trace, launch-per-stage plan (--plan staged; rc_set_fused 0: separate gather / MLP kernels)")
 if os.path.exists(os.path.join(O, "material", "material_kernel_stats.csv")):
     stats(os.path.join(O, "material", "material_kernel_stats.csv"), "kernel trace, material stage (tools/bench_material.py: 1024 primary rays, 32 768 secondary rays per step)", 26)
