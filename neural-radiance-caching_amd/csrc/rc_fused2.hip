@@ -367,41 +367,51 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
   auto jac_at = [&](int e) -> float& { return act_ray[(kJac + (e >> 1)) * 64 + j + 32 * (e & 1)]; };
   {
     // half-wave 0 looks up the level-2 density grid, half-wave 1 the appearance grid (interleaved pair tables);
-    // wave q takes grid levels 4 q .. 4 q + 3: 32 corner loads of 16 bytes in flight per lane
+    // wave q takes grid levels 4 q .. 4 q + 3: 32 corner loads of 16 bytes in flight per lane.  The body is expanded
+    // once per role (QQ is a constant inside): level records, table pointers and the LDS slots of the features and of
+    // the Jacobian are then constants / scalar loads instead of runtime address arithmetic on every store.
     const RcGridDev& g = a.grid[2];
     const float ux = unit_box(g.bbox, cx), uy = unit_box(g.bbox, cy), uz = unit_box(g.bbox, cz);
-    Corners<4> C[4];
+    auto lookup = [&](auto QQ) {
+      constexpr int qq = decltype(QQ)::value;
+      Corners<4> C[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int l = 4 * q + k;
-      const RcGridLevel& L = a.grid[2].lvl[l];
-      grid_fetch<4, true, 2, true>(a.pair_table[l] + 4 * h, L.size, L.mask, 0u, L.dense != 0, ux, uy, uz, C[k]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const int base = h == 0 ? 0 : kAppTmp;
+      for (int k = 0; k < 4; ++k) {
+        const int l = 4 * qq + k;
+        const RcGridLevel& L = a.grid[2].lvl[l];
+        grid_fetch<4, true, 2, true>(a.pair_table[l] + 4 * h, L.size, L.mask, 0u, L.dense != 0, ux, uy, uz, C[k]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const int base = h == 0 ? 0 : kAppTmp;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int l = 4 * q + k;
-      const int size = a.grid[2].lvl[l].size;
-      const bool dense = a.grid[2].lvl[l].dense != 0;
-      float v[4], jd[GRAD ? 12 : 1];
-      grid_combine<4, GRAD>(C[k], v, jd);
-      // feature kf = 4 l + c of point j -> step base + kf / 2, lane j + 32 (kf & 1)
+      for (int k = 0; k < 4; ++k) {
+        const int l = 4 * qq + k;
+        const int size = a.grid[2].lvl[l].size;
+        const bool dense = a.grid[2].lvl[l].dense != 0;
+        float v[4], jd[GRAD ? 12 : 1];
+        grid_combine<4, GRAD>(C[k], v, jd);
+        // feature kf = 4 l + c of point j -> step base + kf / 2, lane j + 32 (kf & 1)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) act_ray[(base + 2 * l + (c >> 1)) * 64 + j + 32 * (c & 1)] = v[c] * g.precondition;
-      if constexpr (GRAD) {
-        const float s = g.precondition * (float)size / (2.0f * g.bbox);
-        if (h == 0) {
+        for (int c = 0; c < 4; ++c) act_ray[(base + 2 * l + (c >> 1)) * 64 + j + 32 * (c & 1)] = v[c] * g.precondition;
+        if constexpr (GRAD) {
+          const float s = g.precondition * (float)size / (2.0f * g.bbox);
+          if (h == 0) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            jac_at(0 * 32 + 4 * l + c) = (dense ? jd[2 * 4 + c] : jd[0 * 4 + c]) * s;
-            jac_at(1 * 32 + 4 * l + c) = jd[1 * 4 + c] * s;
-            jac_at(2 * 32 + 4 * l + c) = (dense ? jd[0 * 4 + c] : jd[2 * 4 + c]) * s;
+            for (int c = 0; c < 4; ++c) {
+              jac_at(0 * 32 + 4 * l + c) = (dense ? jd[2 * 4 + c] : jd[0 * 4 + c]) * s;
+              jac_at(1 * 32 + 4 * l + c) = jd[1 * 4 + c] * s;
+              jac_at(2 * 32 + 4 * l + c) = (dense ? jd[0 * 4 + c] : jd[2 * 4 + c]) * s;
+            }
           }
         }
       }
+    };
+    if (q == 0) {
+      lookup(std::integral_constant<int, 0>{});
+      act[16 * 64] = h == 0 ? 1.0f : 0.0f;
+    } else {
+      lookup(std::integral_constant<int, 1>{});
     }
-    if (q == 0) act[16 * 64] = h == 0 ? 1.0f : 0.0f;
   }
   TB();
   RC_FSTAMP(8);
@@ -625,68 +635,75 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
     for (int c = 0; c < 3; ++c) amb[c] = fmaxf(softplus(o[c] + k.slf_ambient_bias), 0.0f);      // slf.py:1053-1059
   }
   RC_FSTAMP(10);
-  if (q != 0) return;                                // no barrier behind this point
-  ShadeOut so;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    // nerf.py:1034-1053; ambient_specular is an exact 0 (ref_acc == 1)
-    const float is = fminf(fmaxf(tint[c] * ibrdf * (amb[c] * 1.0f), 0.0f), k.rgb_max);
-    const float ambient = ad[c] + 0.0f;
-    const float indirect = idf[c] + is;
-    so.rgb[c] = ambient + indirect; so.ad[c] = ad[c]; so.idf[c] = idf[c]; so.is[c] = is; so.tint[c] = tint[c];
-  }
-  // ------------------------------------------------------------------ volume compositing (k_composite), wave 0
+  // ------------------------------------------------------------------ volume compositing (k_composite): no barrier
+  // behind this point.  Both waves hold the density, the fence posts and the predicted normals of all 32 samples, so the
+  // weighted sums are split: wave 0 the colours (it has the heads) and the analytic normals, wave 1 the geometry
+  // (means, distances, predicted normals) and the distance percentiles.  Same sums in the same order as one wave.
   const bool act_s = lane < 32;
   const float wnf = alpha_weight(density, t0, t1, dnorm, act_s, lane);
   auto store3 = [&](int id, float x, float y, float z) {
     if (lane == 0 && ray_ok && a.out.ptr[id]) { a.out.ptr[id][3 * ray] = x; a.out.ptr[id][3 * ray + 1] = y; a.out.ptr[id][3 * ray + 2] = z; }
   };
   auto store1 = [&](int id, float x) { if (lane == 0 && ray_ok && a.out.ptr[id]) a.out.ptr[id][ray] = x; };
-  enum { V_ACC = 0, V_RGB = 1, V_AD = 4, V_IDF = 7, V_IS = 10, V_TINT = 13, V_DIF = 16, V_IND = 19, V_MEAN = 22, V_RD = 25,
-         V_LD = 26, V_NP = 27, V_NG = 30, V_LOGT = 33, V_COUNT = 34 };
-  float v[V_COUNT];
-  v[V_ACC] = wnf;
+  if (q == 0) {
+    ShadeOut so;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float v_rgb = act_s ? so.rgb[c] : 0.0f, v_ad = act_s ? so.ad[c] : 0.0f, v_id = act_s ? so.idf[c] : 0.0f;
-    const float v_is = act_s ? so.is[c] : 0.0f, v_t = act_s ? so.tint[c] : 0.0f;
-    v[V_RGB + c] = wnf * v_rgb;
-    v[V_AD + c] = wnf * v_ad;
-    v[V_IDF + c] = wnf * v_id;
-    v[V_IS + c] = wnf * v_is;
-    v[V_TINT + c] = wnf * v_t;
-    v[V_DIF + c] = wnf * (v_ad + v_id);
-    v[V_IND + c] = wnf * (v_id + v_is);
-  }
-  v[V_MEAN] = wnf * mx; v[V_MEAN + 1] = wnf * my; v[V_MEAN + 2] = wnf * mz;
-  v[V_RD] = wnf * sqrtf((ox - mx) * (ox - mx) + (oy - my) * (oy - my) + (oz - mz) * (oz - mz));
-  v[V_LD] = 0.0f;
-  if (a.lights) {
-    const float lx = a.lights[3 * ray], ly = a.lights[3 * ray + 1], lz = a.lights[3 * ray + 2];
-    v[V_LD] = wnf * sqrtf((lx - mx) * (lx - mx) + (ly - my) * (ly - my) + (lz - mz) * (lz - mz));
-  }
-  v[V_NP] = wnf * npx; v[V_NP + 1] = wnf * npy; v[V_NP + 2] = wnf * npz;
-  v[V_NG] = wnf * ngx; v[V_NG + 1] = wnf * ngy; v[V_NG + 2] = wnf * ngz;
-  v[V_LOGT] = act_s ? wnf * logf(0.5f * (t0 + t1)) : 0.0f;
-  wave_sum_n<V_COUNT>(v);
-  const float accw = v[V_ACC];
-  const float bgw = fmaxf(0.0f, 1.0f - accw) * a.bg;
-  store3(RC_OUT_RGB, v[V_RGB] + bgw, v[V_RGB + 1] + bgw, v[V_RGB + 2] + bgw);
-  store3(RC_OUT_DIRECT_RGB, v[V_AD], v[V_AD + 1], v[V_AD + 2]);
-  store3(RC_OUT_INDIRECT_DIFFUSE_RGB, v[V_IDF], v[V_IDF + 1], v[V_IDF + 2]);
-  store3(RC_OUT_INDIRECT_SPECULAR_RGB, v[V_IS], v[V_IS + 1], v[V_IS + 2]);
-  store3(RC_OUT_SPECULAR_RGB, v[V_IS], v[V_IS + 1], v[V_IS + 2]);
-  store3(RC_OUT_ALBEDO_RGB, v[V_TINT], v[V_TINT + 1], v[V_TINT + 2]);
-  store3(RC_OUT_DIFFUSE_RGB, v[V_DIF], v[V_DIF + 1], v[V_DIF + 2]);
-  store3(RC_OUT_INDIRECT_RGB, v[V_IND], v[V_IND + 1], v[V_IND + 2]);
-  store3(RC_OUT_INDIRECT_OCC, accw, accw, accw);
-  store1(RC_OUT_ACC, accw);
-  store3(RC_OUT_MEANS, v[V_MEAN], v[V_MEAN + 1], v[V_MEAN + 2]);
-  store1(RC_OUT_RAY_DISTS, v[V_RD]);
-  if (a.lights) store1(RC_OUT_LIGHT_DISTS, v[V_LD]);
-  store3(RC_OUT_NORMALS_PRED, v[V_NP], v[V_NP + 1], v[V_NP + 2]);
-  if constexpr (GRAD) store3(RC_OUT_NORMALS, v[V_NG], v[V_NG + 1], v[V_NG + 2]);
-  {
+    for (int c = 0; c < 3; ++c) {
+      // nerf.py:1034-1053; ambient_specular is an exact 0 (ref_acc == 1)
+      const float is = fminf(fmaxf(tint[c] * ibrdf * (amb[c] * 1.0f), 0.0f), k.rgb_max);
+      const float ambient = ad[c] + 0.0f;
+      const float indirect = idf[c] + is;
+      so.rgb[c] = ambient + indirect; so.ad[c] = ad[c]; so.idf[c] = idf[c]; so.is[c] = is; so.tint[c] = tint[c];
+    }
+    enum { V_ACC = 0, V_RGB = 1, V_AD = 4, V_IDF = 7, V_IS = 10, V_TINT = 13, V_DIF = 16, V_IND = 19, V_NG = 22, V_COUNT = 25 };
+    float v[V_COUNT];
+    v[V_ACC] = wnf;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v_rgb = act_s ? so.rgb[c] : 0.0f, v_ad = act_s ? so.ad[c] : 0.0f, v_id = act_s ? so.idf[c] : 0.0f;
+      const float v_is = act_s ? so.is[c] : 0.0f, v_t = act_s ? so.tint[c] : 0.0f;
+      v[V_RGB + c] = wnf * v_rgb;
+      v[V_AD + c] = wnf * v_ad;
+      v[V_IDF + c] = wnf * v_id;
+      v[V_IS + c] = wnf * v_is;
+      v[V_TINT + c] = wnf * v_t;
+      v[V_DIF + c] = wnf * (v_ad + v_id);
+      v[V_IND + c] = wnf * (v_id + v_is);
+    }
+    v[V_NG] = wnf * ngx; v[V_NG + 1] = wnf * ngy; v[V_NG + 2] = wnf * ngz;
+    wave_sum_n<V_COUNT>(v);
+    const float accw = v[V_ACC];
+    const float bgw = fmaxf(0.0f, 1.0f - accw) * a.bg;
+    store3(RC_OUT_RGB, v[V_RGB] + bgw, v[V_RGB + 1] + bgw, v[V_RGB + 2] + bgw);
+    store3(RC_OUT_DIRECT_RGB, v[V_AD], v[V_AD + 1], v[V_AD + 2]);
+    store3(RC_OUT_INDIRECT_DIFFUSE_RGB, v[V_IDF], v[V_IDF + 1], v[V_IDF + 2]);
+    store3(RC_OUT_INDIRECT_SPECULAR_RGB, v[V_IS], v[V_IS + 1], v[V_IS + 2]);
+    store3(RC_OUT_SPECULAR_RGB, v[V_IS], v[V_IS + 1], v[V_IS + 2]);
+    store3(RC_OUT_ALBEDO_RGB, v[V_TINT], v[V_TINT + 1], v[V_TINT + 2]);
+    store3(RC_OUT_DIFFUSE_RGB, v[V_DIF], v[V_DIF + 1], v[V_DIF + 2]);
+    store3(RC_OUT_INDIRECT_RGB, v[V_IND], v[V_IND + 1], v[V_IND + 2]);
+    store3(RC_OUT_INDIRECT_OCC, accw, accw, accw);
+    store1(RC_OUT_ACC, accw);
+    if constexpr (GRAD) store3(RC_OUT_NORMALS, v[V_NG], v[V_NG + 1], v[V_NG + 2]);
+  } else {
+    enum { V_ACC = 0, V_MEAN = 1, V_RD = 4, V_LD = 5, V_NP = 6, V_LOGT = 9, V_COUNT = 10 };
+    float v[V_COUNT];
+    v[V_ACC] = wnf;
+    v[V_MEAN] = wnf * mx; v[V_MEAN + 1] = wnf * my; v[V_MEAN + 2] = wnf * mz;
+    v[V_RD] = wnf * sqrtf((ox - mx) * (ox - mx) + (oy - my) * (oy - my) + (oz - mz) * (oz - mz));
+    v[V_LD] = 0.0f;
+    if (a.lights) {
+      const float lx = a.lights[3 * ray], ly = a.lights[3 * ray + 1], lz = a.lights[3 * ray + 2];
+      v[V_LD] = wnf * sqrtf((lx - mx) * (lx - mx) + (ly - my) * (ly - my) + (lz - mz) * (lz - mz));
+    }
+    v[V_NP] = wnf * npx; v[V_NP + 1] = wnf * npy; v[V_NP + 2] = wnf * npz;
+    v[V_LOGT] = act_s ? wnf * logf(0.5f * (t0 + t1)) : 0.0f;
+    wave_sum_n<V_COUNT>(v);
+    const float accw = v[V_ACC];
+    store3(RC_OUT_MEANS, v[V_MEAN], v[V_MEAN + 1], v[V_MEAN + 2]);
+    store1(RC_OUT_RAY_DISTS, v[V_RD]);
+    if (a.lights) store1(RC_OUT_LIGHT_DISTS, v[V_LD]);
+    store3(RC_OUT_NORMALS_PRED, v[V_NP], v[V_NP + 1], v[V_NP + 2]);
     const float e = v[V_LOGT] / fmaxf(RC_EPS, accw);
     float dm = expf(e);
     if (dm != dm) dm = INFINITY;
@@ -705,6 +722,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
       const int id = lane == 0 ? RC_OUT_DISTANCE_PERCENTILE_5 : (lane == 1 ? RC_OUT_DISTANCE_MEDIAN : RC_OUT_DISTANCE_PERCENTILE_95);
       if (a.out.ptr[id]) a.out.ptr[id][ray] = pv;
     }
+    return;
   }
   RC_FSTAMP(11);
 #ifdef RC_STAMPS
