@@ -42,7 +42,12 @@ constexpr int kNF = NF_FUSED;
 // Hand-off barrier between the two waves of a ray (all four waves of the workgroup take it).  Its release fence also
 // drains vmcnt, i.e. waits for the ring's LDS-DMA in flight; a barrier that only waits for this wave's LDS writes
 // ("s_waitcnt lgkmcnt(0); s_barrier") was measured 1.2 % SLOWER (127.6 vs 126.1 us per launch).
+#ifdef RC_STAMPS
+// diagnostic build: cycles this wave spends in hand-off barriers (arrival skew + the fence's drain), summed per wave
+#define TB() do { const unsigned long long tb0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); tb_wait += __builtin_amdgcn_s_memtime() - tb0_; ++tb_count; } while (0)
+#else
 #define TB() __syncthreads()
+#endif
 
 // ---- ring helpers with this kernel's geometry
 __device__ __forceinline__ float tw_read(const WStream& w, int f) { return ws_read<kNF, kTW, kTCH>(w, f); }
@@ -243,6 +248,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
   ws.g = a.wstream; ws.ring = ring; ws.lane = lane; ws.wave = wave;
 #ifdef RC_STAMPS
   unsigned long long stamps[16];
+  unsigned long long tb_wait = 0, tb_count = 0;
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
   // Stagger (see rc_launch_fused_team): the workgroups that share a CU run the same phases at the same time -- all of
@@ -733,7 +739,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
     unsigned long long* d = a.stamps + ray * 16;
     for (int i = 0; i < 12; ++i) d[i] = stamps[i];
     d[14] = rt0; d[15] = __builtin_amdgcn_s_memrealtime();
-    d[12] = (unsigned long long)blockIdx.x; d[13] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    d[12] = tb_wait; d[13] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | (tb_count << 32);
   }
 #endif
 }

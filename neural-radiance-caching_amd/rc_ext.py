@@ -450,7 +450,7 @@ class RadianceCache:
             total += (n * width + 63) // 64 * 64
         return max(total, 1), offs, ids
 
-    def render_chunk(self, rays: Dict[str, object], randoms, pass_mask: int, plan):
+    def render_chunk(self, rays: Dict[str, object], randoms, pass_mask: int, plan, out_flat=None, stream_handle=None):
         """rc_render_rays into one fresh flat buffer laid out by `plan` (output_plan).  The hot-loop variant of
         render_rays: device-resident float32 ray fields are passed by pointer as they are (no reshape / copy), the
         outputs are not wrapped into per-key tensors.  Returns (flat tensor, n)."""
@@ -488,12 +488,14 @@ class RadianceCache:
                 rnd.resample_inds = t.data_ptr()
             rnd_p = C.byref(rnd)
         total, _, ids = plan
-        flat = torch.zeros(total, dtype=torch.float32, device=held[0].device)
+        # out_flat: a zero-filled float32 cuda buffer of `total` elements the caller provides (a row of its arena)
+        flat = torch.zeros(total, dtype=torch.float32, device=held[0].device) if out_flat is None else out_flat
         base = flat.data_ptr()
         cout = rc_outputs()
         for oid, off in ids:
             cout.ptr[oid] = base + 4 * off
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        # stream_handle: the raw hipStream_t to enqueue on (a caller that alternates streams skips torch's context manager)
+        stream = torch.cuda.current_stream(self.device).cuda_stream if stream_handle is None else stream_handle
         self._check(self.lib.rc_render_rays(self._h, C.byref(r), n, rnd_p, pass_mask, C.byref(cout), stream))
         self._keep = held          # inputs stay alive until the next call (async enqueue)
         return flat, n

@@ -61,7 +61,10 @@ if os.environ.get("RC_STAMP_DETAIL"):
     order = np.argsort(rt_end)
     print("  10 last rays:", [(int(i), round(float(rt_end[i]), 1)) for i in order[-10:]])
     half = blk >= (n // 4)
-    hw = d[:, 13].astype(np.int64)
+    hw = d[:, 13].astype(np.int64) & 0xffffffff
+    print("  hand-off barriers of wave 0: count", int(np.median(d[:, 13].astype(np.int64) >> 32)), " cycles waited: median %.0f = %.2f us, p95 %.2f us" % (np.median(d[:, 12]), np.median(d[:, 12]) / ghz / 1e3, np.percentile(d[:, 12], 95) / ghz / 1e3))
+    for nm2, sel in (("first half", blk < (n // 4)), ("second half", blk >= (n // 4))):
+        print(f"    [{nm2}] waited median {np.median(d[sel, 12]) / ghz / 1e3:.2f} us")
     if hw.any():       # HW_REG_HW_ID of wave 0 of each ray: SIMD_ID bits 5:4, CU_ID 11:8, SH_ID 12, SE_ID 15:13
         simd = (hw >> 4) & 3
         cu = (hw >> 8) & 0xff
