@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
   // 3: the younger in the shader only, measured 129.9 / 129.9 / 128.5).  Wrong guesses about who shares a CU cost nothing.
   const bool young = blockIdx.x >= (gridDim.x >> 1);
   const int pm = a.prio_mode & 7;
-  if (young && (pm == 1 || pm == 2)) __builtin_amdgcn_s_setprio(1);
+  if ((young && (pm == 1 || pm == 2)) || pm == 5) __builtin_amdgcn_s_setprio(1);
   if (!young && pm == 4) __builtin_amdgcn_s_setprio(1);
   RC_FSTAMP(0);
   ws_begin<kNF, kTW, kTCH>(ws);
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
     }
   }
   RC_FSTAMP(9);
-  if (young && pm == 1) __builtin_amdgcn_s_setprio(0);
+  if ((young && pm == 1) || pm == 5) __builtin_amdgcn_s_setprio(0);
   if (young && pm == 3) __builtin_amdgcn_s_setprio(1);
   // ------------------------------------------------------------------ shader on the 32 samples (rc_dev_mlp.h shader_tile)
   constexpr int F0 = F_SH;
@@ -756,6 +756,10 @@ void rc_launch_fused_team(const RcFusedArgs& a, bool grad, hipStream_t stream) {
   }
   dim3 grid((unsigned)((a.n + 1) / 2)), block(kTW * 64);
   RcFusedArgs b = a;
+  // the priority scheme reads "second half of the grid" as "dispatched second onto its CU": true while the whole grid is
+  // resident at once (two workgroups per CU); beyond that workgroups start as others finish and the scheme costs
+  // 2.4 % (16 384 rays: 1790 -> 1833 us), so it is switched off
+  if ((int64_t)grid.x > 2 * (int64_t)rc_device_cus()) b.prio_mode = 0;
   if (b.stagger_cycles > 0) {
     static std::atomic<int32_t*> slots{nullptr};       // one process drives one GPU (one handle per device)
     int32_t* p = slots.load();
