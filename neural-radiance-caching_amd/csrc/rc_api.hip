@@ -316,6 +316,11 @@ bool fused_geometry_ok(rc_handle* h) {
   for (int g = 0; g < 4 && ok; ++g)        // hashed levels: power-of-two tables only (index = hash & mask)
     for (int l = 0; l < h->grids[g].dev.num_levels && ok; ++l)
       ok = h->grids[g].dev.lvl[l].dense || h->grids[g].dev.lvl[l].mask != 0;
+  // the kernels are compiled for the reference's level layout (16 ... 2048 cells a side against 2^19 entries): the
+  // first kRcFusedDenseLevels levels dense, the others hashed (the kind of a level is a compile-time constant there)
+  for (int g = 0; g < 4 && ok; ++g)
+    for (int l = 0; l < h->grids[g].dev.num_levels && ok; ++l)
+      ok = (h->grids[g].dev.lvl[l].dense != 0) == (l < kRcFusedDenseLevels);
   return ok;
 }
 

@@ -2,12 +2,29 @@
 // rc_fused.hip).  See rc_hashgrid.hip for the reference mapping.
 #pragma once
 #include "rc_internal.h"
+#include <type_traits>
+#include <utility>
 
 namespace rcdev {
 
 
 constexpr uint32_t kPi2 = 19349663u;   // grid_utils.py:102
 constexpr uint32_t kPi3 = 83492791u;   // grid_utils.py:103
+
+// compile-time loop: body(std::integral_constant<int, I>) for I in [0, N) -- expanded in the AST, so the fragment
+// indices are constants whatever the optimizer's unroll budget says (a rolled k-loop turns the operand register sets
+// into runtime-indexed ones, tools/isa_scan.py)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& body, std::integer_sequence<int, I...>) { (body(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& body) { static_for_impl(body, std::make_integer_sequence<int, N>{}); }
+
+// Value of the second (half != 0) or first argument, BY VALUE: a conditional on two struct members is an lvalue, for
+// which the compiler selects the address and loads per lane; two values in scalar registers become one v_cndmask.
+template <class T>
+__device__ __forceinline__ T pick_half(int half, T first, T second) { return half ? second : first; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int F> struct Vec;
 template <> struct Vec<1> { float v[1]; };
@@ -58,74 +75,96 @@ template <int F> struct Corners { Vec<F> val[8]; float cw[3]; uint32_t zero_mask
 // x01 = (x - bbox_min) / (bbox_max - bbox_min) (grid_utils.py:820, 863)
 __device__ __forceinline__ float unit_box(float bbox, float x) { return rc_div(x - (-bbox), bbox - (-bbox)); }
 
+// Cell of a dense level in its cell table (built by the host: for every cell origin of the zero-padded volume, (N + 3)^3
+// of them, the 8 corner entries in combine order, zeros for the padding already in place) and the three interpolation
+// weights: trilerp 'grid' branch, flip(coords - 0.5) then +1 for the zero padding (grid_utils.py:711, 390).
+__device__ __forceinline__ uint32_t cell_index(int size, float x01, float y01, float z01, float (&cw)[3]) {
+  const float N = (float)size;
+  const float cx = x01 * N, cy = y01 * N, cz = z01 * N;     // x01 * grid_size (grid_utils.py:820, 863)
+  const float loc[3] = {(cz - 0.5f) + 1.0f, (cy - 0.5f) + 1.0f, (cx - 0.5f) + 1.0f};
+  int base[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float fl = floorf(loc[a]);
+    cw[a] = loc[a] - fl;
+    base[a] = (int)fl;
+  }
+  // cell origin clamped to [-1, N + 1]: beyond that both corners of an axis are padding anyway
+  const int M = size + 3;
+  const int q0 = min(max(base[0], -1), size + 1) + 1, q1 = min(max(base[1], -1), size + 1) + 1,
+            q2 = min(max(base[2], -1), size + 1) + 1;
+  return ((uint32_t)q2 * (uint32_t)M + (uint32_t)q1) * (uint32_t)M + (uint32_t)q0;
+}
+
+// A dense F = 1 level through its cell table when the WHOLE WAVE is on such a level: a lane reads its 8 corners as two
+// 16-byte loads of one 32-byte block instead of four scattered line pairs, and the clamp / zero-mask arithmetic per
+// corner disappears.  (Vector-typed loads: HIP's float4 is a struct whose load is split into four scalar loads, which the
+// optimizer then merges with a hashed side's eight corner loads behind a branch -- eight 4-byte loads of one block,
+// four times the sector look-ups.)
+__device__ __forceinline__ void grid_fetch_cell(const float* __restrict__ cell_table, int size, float x01, float y01, float z01,
+                                                Corners<1>& C) {
+  C.zero_mask = 0;
+  const uint32_t cell = cell_index(size, x01, y01, z01, C.cw);
+  const f32x4* cp = reinterpret_cast<const f32x4*>(cell_table) + (size_t)cell * 2;
+  const f32x4 lo = cp[0], hi = cp[1];
+  C.val[0].v[0] = lo.x; C.val[1].v[0] = lo.y; C.val[2].v[0] = lo.z; C.val[3].v[0] = lo.w;
+  C.val[4].v[0] = hi.x; C.val[5].v[0] = hi.y; C.val[6].v[0] = hi.z; C.val[7].v[0] = hi.w;
+}
+
 // POW2: the caller guarantees power-of-two hash tables (mask != 0): no modulo path.
 // STRIDE: distance between consecutive entries in units of F floats (2 for the interleaved [density | appearance]
 // tables of the fused kernel, where `table` already points at this lane's half of an entry pair).
-// CELL (dense levels of the fused kernel): `table` is a cell table built by the host -- for every cell origin of the
-// zero-padded volume, (N + 3)^3 of them, the 8 corner entries in combine order, zeros for the padding already in
-// place -- so a lane reads its 8 corners from ONE contiguous block (32 bytes for F = 1: two 16-byte loads; with
-// STRIDE = 2 a 256-byte block of [density | appearance] pairs) instead of four scattered line pairs, and the clamp /
-// zero-mask arithmetic per corner disappears.
+// CELL: a dense level's `table` is its cell table (cell_index; with STRIDE = 2 a 256-byte block of [density | appearance]
+// pairs per cell).
+// `dense` may differ between the two half-waves of a wave (the level kernels split a point's levels by parity): the two
+// sides then run one after the other under exec masks and only compute the eight entry INDICES; the eight loads are
+// common code behind them -- loads inside the sides target the same registers and would wait for each other.
 template <int F, bool POW2 = false, int STRIDE = 1, bool CELL = false>
 __device__ __forceinline__ void grid_fetch(const float* __restrict__ table, int size, uint32_t mask, uint32_t entries,
                                            bool dense, float x01, float y01, float z01, Corners<F>& C) {
-  const float N = (float)size;
-  // x01 * grid_size (grid_utils.py:820, 863)
-  const float cx = x01 * N;
-  const float cy = y01 * N;
-  const float cz = z01 * N;
   C.zero_mask = 0;
+  uint32_t idx[8];
   if (dense) {
-    // trilerp 'grid' branch: flip(coords - 0.5) then +1 for the zero padding (grid_utils.py:711, 390)
-    const float loc[3] = {(cz - 0.5f) + 1.0f, (cy - 0.5f) + 1.0f, (cx - 0.5f) + 1.0f};
-    int base[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float fl = floorf(loc[a]);
-      C.cw[a] = loc[a] - fl;
-      base[a] = (int)fl;
-    }
     if constexpr (CELL) {
-      // cell origin clamped to [-1, N + 1]: beyond that both corners of an axis are padding anyway
-      const int M = size + 3;
-      const int q0 = min(max(base[0], -1), size + 1) + 1, q1 = min(max(base[1], -1), size + 1) + 1,
-                q2 = min(max(base[2], -1), size + 1) + 1;
-      const uint32_t cell = ((uint32_t)q2 * (uint32_t)M + (uint32_t)q1) * (uint32_t)M + (uint32_t)q0;
-      if constexpr (F == 1 && STRIDE == 1) {
-        const float4* cp = reinterpret_cast<const float4*>(table) + (size_t)cell * 2;
-        const float4 lo = cp[0], hi = cp[1];
-        C.val[0].v[0] = lo.x; C.val[1].v[0] = lo.y; C.val[2].v[0] = lo.z; C.val[3].v[0] = lo.w;
-        C.val[4].v[0] = hi.x; C.val[5].v[0] = hi.y; C.val[6].v[0] = hi.z; C.val[7].v[0] = hi.w;
-      } else {
+      const uint32_t cell = cell_index(size, x01, y01, z01, C.cw);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) C.val[c] = load_entry<F>(table, (cell * 8u + (uint32_t)c) * STRIDE);
+      for (int c = 0; c < 8; ++c) idx[c] = cell * 8u + (uint32_t)c;
+    } else {
+      const float N = (float)size;
+      const float cx = x01 * N, cy = y01 * N, cz = z01 * N;     // x01 * grid_size (grid_utils.py:820, 863)
+      // trilerp 'grid' branch: flip(coords - 0.5) then +1 for the zero padding (grid_utils.py:711, 390)
+      const float loc[3] = {(cz - 0.5f) + 1.0f, (cy - 0.5f) + 1.0f, (cx - 0.5f) + 1.0f};
+      int base[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float fl = floorf(loc[a]);
+        C.cw[a] = loc[a] - fl;
+        base[a] = (int)fl;
       }
-      return;
-    }
-    // clamp to the padded volume [0, N+1]; the pad (0 and N+1) holds zeros (grid_utils.py:384-390, 435-438);
-    // data[loc2, loc1, loc0] = grid[x, y, z]: idx = ((k2-1) N + (k1-1)) N + (k0-1)
-    uint32_t term[3][2];
-    bool out[3][2];
+      // clamp to the padded volume [0, N+1]; the pad (0 and N+1) holds zeros (grid_utils.py:384-390, 435-438);
+      // data[loc2, loc1, loc0] = grid[x, y, z]: idx = ((k2-1) N + (k1-1)) N + (k0-1)
+      uint32_t term[3][2];
+      bool out[3][2];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+      for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int k = min(max(base[a] + b, 0), size + 1);
-        out[a][b] = (k < 1) | (k > size);
-        const uint32_t km = (uint32_t)(k - 1);
-        term[a][b] = a == 0 ? km : (a == 1 ? km * (uint32_t)size : km * (uint32_t)size * (uint32_t)size);
+        for (int b = 0; b < 2; ++b) {
+          const int k = min(max(base[a] + b, 0), size + 1);
+          out[a][b] = (k < 1) | (k > size);
+          const uint32_t km = (uint32_t)(k - 1);
+          term[a][b] = a == 0 ? km : (a == 1 ? km * (uint32_t)size : km * (uint32_t)size * (uint32_t)size);
+        }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int b0 = (c >> 2) & 1, b1 = (c >> 1) & 1, b2 = c & 1;
+        const bool zero = out[0][b0] | out[1][b1] | out[2][b2];
+        idx[c] = zero ? 0u : term[2][b2] + term[1][b1] + term[0][b0];
+        C.zero_mask |= (zero ? 1u : 0u) << c;
       }
-    // fetch order: the two corners that differ in b0 (adjacent entries, almost always one cache line) back to back
-#pragma unroll
-    for (int o = 0; o < 8; ++o) {
-      const int c = ((o & 1) << 2) | (o >> 1);
-      const int b0 = (c >> 2) & 1, b1 = (c >> 1) & 1, b2 = c & 1;
-      const bool zero = out[0][b0] | out[1][b1] | out[2][b2];
-      const uint32_t idx = zero ? 0u : term[2][b2] + term[1][b1] + term[0][b0];
-      C.zero_mask |= (zero ? 1u : 0u) << c;
-      C.val[c] = load_entry<F>(table, idx * STRIDE);
     }
   } else {
+    const float N = (float)size;
+    const float cx = x01 * N, cy = y01 * N, cz = z01 * N;       // x01 * grid_size (grid_utils.py:820, 863)
     const float loc[3] = {cx - 0.5f, cy - 0.5f, cz - 0.5f};     // grid_utils.py:61
     int base[3];
 #pragma unroll
@@ -138,15 +177,101 @@ __device__ __forceinline__ void grid_fetch(const float* __restrict__ table, int 
     const uint32_t hx[2] = {(uint32_t)base[0], (uint32_t)base[0] + 1u};
     const uint32_t y0 = (uint32_t)base[1] * kPi2, z0 = (uint32_t)base[2] * kPi3;
     const uint32_t hy[2] = {y0, y0 + kPi2}, hz[2] = {z0, z0 + kPi3};
-    // fetch order: x and x + 1 (index differs in the low bits only: same cache line 7 times out of 8) back to back
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
-      const int c = ((o & 1) << 2) | (o >> 1);
+    for (int c = 0; c < 8; ++c) {
       const int b0 = (c >> 2) & 1, b1 = (c >> 1) & 1, b2 = c & 1;
       const uint32_t hsh = hx[b0] ^ hy[b1] ^ hz[b2];
-      const uint32_t idx = (POW2 || mask) ? (hsh & mask) : (hsh % entries);
-      C.val[c] = load_entry<F>(table, idx * STRIDE);
+      idx[c] = (POW2 || mask) ? (hsh & mask) : (hsh % entries);
     }
+  }
+  // fetch order: the two corners that differ in b0 -- x and x + 1: adjacent entries of a dense level, an index that
+  // differs in the low bits only on a hashed one (same cache line 7 times out of 8) -- back to back
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    const int c = ((o & 1) << 2) | (o >> 1);
+    C.val[c] = load_entry<F>(table, idx[c] * STRIDE);
+  }
+}
+
+// ---- A pair of F = 1 levels of one point on the two half-waves of a wave ------------------------------------------
+// The level kernels and the two-wave fused kernel put a point on lanes j and j + 32 and give the lower half-wave the
+// even grid levels to interpolate, the upper one the odd levels (a lane's feature lands in its own MFMA B column).
+// Splitting the LOADS the same way -- half-wave h reads the 8 corners of level 2 i + h -- makes the 64 lanes of every
+// load instruction 64 different sectors, and a pair of levels of different kinds (dense | hashed) two code paths under
+// exec masks.  Here the loads of a pair (A on the lower half, B on the upper half) are split by CORNER instead: every
+// lane reads the four corners with b0 = h (b0: the x bit, corner c = 4 b0 + 2 b1 + b2) of BOTH levels, so lanes j and
+// j + 32 of an instruction read x and x + 1 -- the two halves of a cell's 32-byte block in a cell table, adjacent
+// entries of a hashed table (one 64-byte sector 15 times out of 16): about half the sector look-ups, which is what bounds
+// a random gather (profiles/r03_two_wave_probe.txt), and no divergence, the kinds being compile-time.  When the values
+// have arrived, four v_permlane32_swap hand each half-wave the other four corners of ITS level; grid_combine then adds
+// them in the reference's corner order as before (bitwise the same feature).
+enum : int { kLevelNone = -1, kLevelHashed = 0, kLevelCell = 2 };    // kinds of a level (hashed: power-of-two table)
+
+struct PairCorners { float va[4], vb[4]; float cw[3]; };
+
+// this lane's four corners (b0 = h) of one level: loads issued into v[], interpolation weights of the level into cw[]
+template <int KIND>
+__device__ __forceinline__ void half_corners(const float* __restrict__ table, int size, uint32_t mask, int h, float x01,
+                                             float y01, float z01, float (&cw)[3], float (&v)[4]) {
+  if constexpr (KIND == kLevelCell) {
+    const uint32_t cell = cell_index(size, x01, y01, z01, cw);
+    const f32x4 q = *reinterpret_cast<const f32x4*>(table + (size_t)cell * 8 + 4 * h);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  } else {
+    const float N = (float)size;
+    const float cx = x01 * N, cy = y01 * N, cz = z01 * N;       // x01 * grid_size (grid_utils.py:820, 863)
+    const float loc[3] = {cx - 0.5f, cy - 0.5f, cz - 0.5f};     // grid_utils.py:61
+    int base[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float fl = floorf(loc[a]);
+      cw[a] = loc[a] - fl;
+      base[a] = (int)fl;
+    }
+    // int32 -> uint32 wraparound hash (grid_utils.py:99-111): x ^ y * pi2 ^ z * pi3
+    const uint32_t hx = (uint32_t)base[0] + (uint32_t)h;
+    const uint32_t y0 = (uint32_t)base[1] * kPi2, z0 = (uint32_t)base[2] * kPi3;
+    const uint32_t hy[2] = {y0, y0 + kPi2}, hz[2] = {z0, z0 + kPi3};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = table[(hx ^ hy[(c >> 1) & 1] ^ hz[c & 1]) & mask];
+  }
+}
+
+// issue the loads of the pair (KB == kLevelNone: a single level A, its corners still split between the half-waves)
+template <int KA, int KB>
+__device__ __forceinline__ void pair_fetch(const float* __restrict__ tab_a, int size_a, uint32_t mask_a,
+                                           const float* __restrict__ tab_b, int size_b, uint32_t mask_b, int h, float x01,
+                                           float y01, float z01, PairCorners& P) {
+  float cwa[3], cwb[3];
+  half_corners<KA>(tab_a, size_a, mask_a, h, x01, y01, z01, cwa, P.va);
+  if constexpr (KB != kLevelNone) {
+    half_corners<KB>(tab_b, size_b, mask_b, h, x01, y01, z01, cwb, P.vb);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) P.cw[a] = h ? cwb[a] : cwa[a];
+  } else {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) P.cw[a] = cwa[a];
+  }
+}
+
+// v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second; returns {first, second} afterwards
+__device__ __forceinline__ void swap_halves(float& first, float& second) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(first), __float_as_uint(second), false, false);
+  first = __uint_as_float(r[0]); second = __uint_as_float(r[1]);
+}
+
+// after the loads: the eight corners of this half-wave's level (A on the lower, B on the upper half) in combine order.
+// Lower half: own A corners 0-3 | A corners 4-7 from lane + 32; upper half: B corners 0-3 from lane - 32 | own B corners 4-7.
+template <bool HAS_B>
+__device__ __forceinline__ void pair_finish(const PairCorners& P, Corners<1>& C) {
+  C.zero_mask = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) C.cw[a] = P.cw[a];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float first = P.va[k], second = HAS_B ? P.vb[k] : P.va[k];
+    swap_halves(first, second);
+    C.val[k].v[0] = first; C.val[4 + k].v[0] = second;
   }
 }
 
@@ -204,7 +329,7 @@ __device__ __forceinline__ void grid_level(const RcGridLevel& L, float bbox, flo
   if constexpr (F == 1 && !JAC) {
     // one contiguous 32-byte read per cell instead of eight scattered corners (wave-uniform branch: blockIdx.y = level)
     if (L.cell) {
-      grid_fetch<1, false, 1, true>(L.cell, L.size, L.mask, L.entries, true, unit_box(bbox, x), unit_box(bbox, y), unit_box(bbox, z), C);
+      grid_fetch_cell(L.cell, L.size, unit_box(bbox, x), unit_box(bbox, y), unit_box(bbox, z), C);
       grid_combine<F, JAC>(C, acc, jacc);
       return;
     }

@@ -150,7 +150,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
       Corners<1> C[6];          // all 48 corner loads in flight before the first combine
       RC_FSTAMP(12);
 #pragma unroll
-      for (int l = 0; l < 6; ++l) { const RcGridLevel& L = a.grid[0].lvl[l]; grid_fetch<1, true, 1, true>(L.dense ? a.cell_table[0][l] : L.table, L.size, L.mask, 0u, L.dense != 0, ux, uy, uz, C[l]); }
+      for (int l = 0; l < 6; ++l) {
+        const RcGridLevel& L = a.grid[0].lvl[l];
+        if (L.dense) grid_fetch_cell(a.cell_table[0][l], L.size, ux, uy, uz, C[l]);
+        else grid_fetch<1, true>(L.table, L.size, L.mask, 0u, false, ux, uy, uz, C[l]);
+      }
       RC_FSTAMP_NOWAIT(13);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -188,7 +192,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
 #else
       Corners<1> C[7];          // all 56 corner loads in flight before the first combine
 #pragma unroll
-      for (int l = 0; l < 7; ++l) { const RcGridLevel& L = a.grid[1].lvl[l]; grid_fetch<1, true, 1, true>(L.dense ? a.cell_table[1][l] : L.table, L.size, L.mask, 0u, L.dense != 0, ux, uy, uz, C[l]); }
+      for (int l = 0; l < 7; ++l) {
+        const RcGridLevel& L = a.grid[1].lvl[l];
+        if (L.dense) grid_fetch_cell(a.cell_table[1][l], L.size, ux, uy, uz, C[l]);
+        else grid_fetch<1, true>(L.table, L.size, L.mask, 0u, false, ux, uy, uz, C[l]);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int l = 0; l < 7; ++l) {

@@ -71,14 +71,6 @@ template <> struct TileMap<8> { static constexpr int NTL = 4, QS = 2; static con
 // fragments (wave 0's tile t, wave 1's tile t + QS) are read with ONE runtime-offset read when they sit in the same ring
 // chunk, and under a wave-uniform branch each when a seam separates them (a fragment of chunk c may only be read
 // between the barriers that open chunks c and c + 1).
-// compile-time loop: body(std::integral_constant<int, I>) for I in [0, N) -- expanded in the AST, so the fragment
-// indices are constants whatever the optimizer's unroll budget says (a rolled k-loop turns the operand register sets
-// into runtime-indexed ones, tools/isa_scan.py)
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& body, std::integer_sequence<int, I...>) { (body(std::integral_constant<int, I>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& body) { static_for_impl(body, std::make_integer_sequence<int, N>{}); }
-
 template <int NT, int KS, int FBASE, int SG = (TileMap<NT>::NTL >= 4 ? 2 : (TileMap<NT>::NTL >= 2 ? 4 : 8))>
 __device__ __forceinline__ void mlp_layer_team(const WStream& w, int q, const float* act, f32x16 (&acc)[TileMap<NT>::NTL]) {
   using TM = TileMap<NT>;
@@ -183,30 +175,33 @@ __device__ __forceinline__ float level_tile(const RcFusedArgs& a, const WStream&
   float* act = act_tile + lane;
   const RcGridDev& grid = a.grid[G];
   const float ux = unit_box(grid.bbox, cx), uy = unit_box(grid.bbox, cy), uz = unit_box(grid.bbox, cz);
+  // pair i = grid levels (2 i, 2 i + 1): loads split by corner between the half-waves (rc_dev_grid.h pair_fetch), kinds
+  // compile-time (the fused plan is compiled for kFusedDense leading dense levels, fused_geometry_ok), level records in
+  // scalar registers -- straight-line code, every load of the tile in flight before the first combine
   constexpr int NH = (NL + 1) / 2;
-  Corners<1> C[NH];
-#pragma unroll
-  for (int i = 0; i < NH; ++i) {
-    const int l0 = 2 * i, l1 = 2 * i + 1 < NL ? 2 * i + 1 : 2 * i;
-    const RcGridLevel &L0 = grid.lvl[l0], &L1 = grid.lvl[l1];
-    if (2 * i + 1 < NL || hh == 0) {
-      const bool dense = hh ? L1.dense != 0 : L0.dense != 0;
-      const float* tab = hh ? (L1.dense ? a.cell_table[G][l1] : L1.table) : (L0.dense ? a.cell_table[G][l0] : L0.table);
-      grid_fetch<1, true, 1, true>(tab, hh ? L1.size : L0.size, hh ? L1.mask : L0.mask, 0u, dense, ux, uy, uz, C[i]);
-    }
-  }
+  PairCorners P[NH];
+  static_for<NH>([&](auto I) {
+    constexpr int i = decltype(I)::value, la = 2 * i, lb = 2 * i + 1;
+    constexpr int ka = la < kFusedDense ? kLevelCell : kLevelHashed;
+    constexpr int kb = lb >= NL ? kLevelNone : (lb < kFusedDense ? kLevelCell : kLevelHashed);
+    const RcGridLevel &LA = grid.lvl[la], &LB = grid.lvl[lb < NL ? lb : la];
+    pair_fetch<ka, kb>(ka == kLevelCell ? a.cell_table[G][la] : LA.table, LA.size, LA.mask,
+                       kb == kLevelCell ? a.cell_table[G][lb < NL ? lb : la] : LB.table, LB.size, LB.mask, hh, ux, uy, uz, P[i]);
+  });
   __builtin_amdgcn_sched_barrier(0);
   // feature l of point j -> step l / 2, half l & 1 = hh: this lane's own column
-#pragma unroll
-  for (int i = 0; i < KS0 - 1; ++i) {
+  static_for<KS0 - 1>([&](auto I) {
+    constexpr int i = decltype(I)::value;
     float v = 0.0f;
-    if (i < NH && (2 * i + 1 < NL || hh == 0)) {
+    if constexpr (i < NH) {
+      Corners<1> C;
+      pair_finish<(2 * i + 1 < NL)>(P[i], C);
       float f[1], jd[1];
-      grid_combine<1, false>(C[i < NH ? i : 0], f, jd);
-      v = f[0] * grid.precondition;
+      grid_combine<1, false>(C, f, jd);
+      v = (2 * i + 1 < NL || hh == 0) ? f[0] * grid.precondition : 0.0f;
     }
     act[i * 64] = v;
-  }
+  });
   act[(KS0 - 1) * 64] = hh == 0 ? 1.0f : 0.0f;
   lds_sync<false>();
 #ifdef RC_STAMPS

@@ -11,6 +11,7 @@ using namespace rcdev;
 constexpr int kTileStride = 33 * 64;          // floats between the two point-tiles of levels 0/1
 constexpr int kScratch = 7 * 68;              // per-wave step-function scratch (floats)
 constexpr int kAppTmp = 33;                   // act steps [33, 49): appearance features parked during the density MLP
+constexpr int kFusedDense = kRcFusedDenseLevels;               // grid levels [0, 3) of every grid are dense (16, 32, 64 cells a side), the rest hashed: fused_geometry_ok
 constexpr int kJac = 49;                      // act steps [49, 97): d feature / d position of the level-2 density grid
 
 // fragments of the fused weight stream

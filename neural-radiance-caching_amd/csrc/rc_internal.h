@@ -272,6 +272,9 @@ struct RcFusedLaunch {
   int32_t use_raydist; float raydist_p, raydist_premult;
   float* f_tdist; float* f_density; float* f_means; float* f_normals_pred; float* f_normals_grad; float* f_hbuf; float* f_app;
 };
+// the fused kernels are compiled for this level layout of every grid: levels [0, kRcFusedDenseLevels) dense (16, 32, 64
+// cells a side against 2^19 entries), the others hashed
+constexpr int kRcFusedDenseLevels = 3;
 int rc_fused_stream_offsets(int* l0, int* l1, int* l2, int* sh);   // returns the total fragment count
 void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream);
 // dst[cell][corner][dst_stride floats, written F at dst_off]: the 8 corners of every cell of the zero-padded dense

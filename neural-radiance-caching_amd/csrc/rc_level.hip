@@ -58,7 +58,10 @@ struct RcLevelKArgs {
 };
 
 // NL grid levels of F features: K = NL * F grid features, KS0 = K / 2 (rounded up) + 1 k-steps in layer 0.
-template <int F, int NL>
+// ND >= 0 (F = 1): the level layout is known at compile time -- levels [0, ND) dense with cell tables, the others hashed
+// (the reference's layout has ND = 3) -- and the lookup is rc_dev_grid.h's pair_fetch: loads split by corner between the
+// half-waves, no divergence.  ND = -1: any layout, the kind of a level read from its record.
+template <int F, int NL, int ND = -1>
 struct LevelK {
   static constexpr int W = LevelCfg<F>::W;
   static constexpr int K = F * NL, KS0 = (K + 1) / 2 + 1;
@@ -85,46 +88,92 @@ struct LevelK {
     const float bbox = grid.bbox;
     contract3(cx, cy, cz, contract_radius);
     const float ux = unit_box(bbox, cx), uy = unit_box(bbox, cy), uz = unit_box(bbox, cz);
-    // this half-wave's levels: l = 2 i + h (all their corner loads in flight before the first combine)
-    constexpr int NH = (NL + 1) / 2;
-    Corners<F> C[NH];
-#pragma unroll
-    for (int i = 0; i < NH; ++i) {
-      const int l = 2 * i + h;
-      if (l < NL) {
-        const RcGridLevel& L = grid.lvl[l];
-        if constexpr (F == 1) {
-          if (L.cell) grid_fetch<1, false, 1, true>(L.cell, L.size, L.mask, L.entries, true, ux, uy, uz, C[i]);
-          else grid_fetch<1>(L.table, L.size, L.mask, L.entries, L.dense != 0, ux, uy, uz, C[i]);
-        } else {
-          grid_fetch<4>(L.table, L.size, L.mask, L.entries, L.dense != 0, ux, uy, uz, C[i]);
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (F == 1) {
+    if constexpr (F == 1 && ND >= 0) {
+      constexpr int NH = (NL + 1) / 2;
+      PairCorners P[NH];
+      static_for<NH>([&](auto I) {
+        constexpr int i = decltype(I)::value, la = 2 * i, lb = 2 * i + 1 < NL ? 2 * i + 1 : 2 * i;
+        constexpr int ka = la < ND ? kLevelCell : kLevelHashed;
+        constexpr int kb = 2 * i + 1 >= NL ? kLevelNone : (lb < ND ? kLevelCell : kLevelHashed);
+        const RcGridLevel &LA = grid.lvl[la], &LB = grid.lvl[lb];
+        pair_fetch<ka, kb>(ka == kLevelCell ? LA.cell : LA.table, LA.size, LA.mask, kb == kLevelCell ? LB.cell : LB.table,
+                           LB.size, LB.mask, h, ux, uy, uz, P[i]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
       // feature l of point j -> step l / 2, half l & 1 = h: this lane's own column
-#pragma unroll
-      for (int i = 0; i < KS0 - 1; ++i) {
-        const int l = 2 * i + h;
+      static_for<KS0 - 1>([&](auto I) {
+        constexpr int i = decltype(I)::value;
         float v = 0.0f;
-        if (i < NH && l < NL) {
+        if constexpr (i < NH) {
+          Corners<1> C;
+          pair_finish<(2 * i + 1 < NL)>(P[i], C);
           float f[1], jd[1];
-          grid_combine<1, false>(C[i < NH ? i : 0], f, jd);
-          v = f[0] * grid.precondition;
+          grid_combine<1, false>(C, f, jd);
+          v = (2 * i + 1 < NL || h == 0) ? f[0] * grid.precondition : 0.0f;
         }
         act[i * 64] = v;
-      }
+      });
     } else {
-      // F = 4: feature 4 l + c -> step 2 l + c / 2, half c & 1
+      // this half-wave's levels: l = 2 i + h (all their corner loads in flight before the first combine)
+      constexpr int NH = (NL + 1) / 2;
+      Corners<F> C[NH];
 #pragma unroll
       for (int i = 0; i < NH; ++i) {
         const int l = 2 * i + h;
         if (l < NL) {
-          float f[4], jd[1];
-          grid_combine<4, false>(C[i], f, jd);
+          // Both level records of the pair (kernel arguments) into scalar registers, the half-wave's one selected in
+          // registers: indexing grid.lvl[] with the lane-dependent l makes every field a per-lane global load from the
+          // argument segment -- dependent round trips in front of the corner loads, and their s_waitcnt vmcnt(0) drains
+          // the previous pair's corners, so a lane never had more than one level in flight.  Kind of a level: 2 = dense
+          // with a cell table, 1 = dense, 0 = hashed (power-of-two tables only: rc_level_supported); a pair of one kind
+          // branches wave-uniformly, a mixed pair runs both sides under exec masks.
+          const RcGridLevel &L0 = grid.lvl[2 * i], &L1 = grid.lvl[2 * i + 1 < NL ? 2 * i + 1 : 2 * i];
+          const int size = pick_half(h, L0.size, L1.size);
+          const uint32_t mask = pick_half(h, L0.mask, L1.mask);
+          if constexpr (F == 1) {
+            const int k0 = L0.cell ? 2 : (L0.dense ? 1 : 0), k1 = L1.cell ? 2 : (L1.dense ? 1 : 0);
+            const float* tab = pick_half(h, k0 == 2 ? L0.cell : L0.table, k1 == 2 ? L1.cell : L1.table);
+            if (k0 == k1) {
+              if (k0 == 2) grid_fetch_cell(tab, size, ux, uy, uz, C[i]);
+              else grid_fetch<1, true>(tab, size, mask, 0u, k0 == 1, ux, uy, uz, C[i]);
+            } else if ((k0 == 1) | (k1 == 1)) {
+              grid_fetch<1, true>(pick_half(h, L0.table, L1.table), size, mask, 0u, pick_half(h, k0, k1) != 0, ux, uy, uz, C[i]);   // a dense level without its cell table in the pair: plain tables on both sides
+            } else {
+              grid_fetch<1, true, 1, true>(tab, size, mask, 0u, pick_half(h, k0, k1) == 2, ux, uy, uz, C[i]);
+            }
+          } else {
+            const bool d0 = L0.dense != 0, d1 = L1.dense != 0;
+            const float* tab = pick_half(h, L0.table, L1.table);
+            if (d0 == d1) grid_fetch<4, true>(tab, size, mask, 0u, d0, ux, uy, uz, C[i]);
+            else grid_fetch<4, true>(tab, size, mask, 0u, pick_half(h, d0, d1), ux, uy, uz, C[i]);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (F == 1) {
+        // feature l of point j -> step l / 2, half l & 1 = h: this lane's own column
 #pragma unroll
-          for (int c = 0; c < 4; ++c) act_wave[(2 * l + (c >> 1)) * 64 + j + 32 * (c & 1)] = f[c] * grid.precondition;
+        for (int i = 0; i < KS0 - 1; ++i) {
+          const int l = 2 * i + h;
+          float v = 0.0f;
+          if (i < NH && l < NL) {
+            float f[1], jd[1];
+            grid_combine<1, false>(C[i < NH ? i : 0], f, jd);
+            v = f[0] * grid.precondition;
+          }
+          act[i * 64] = v;
+        }
+      } else {
+        // F = 4: feature 4 l + c -> step 2 l + c / 2, half c & 1
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+          const int l = 2 * i + h;
+          if (l < NL) {
+            float f[4], jd[1];
+            grid_combine<4, false>(C[i], f, jd);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) act_wave[(2 * l + (c >> 1)) * 64 + j + 32 * (c & 1)] = f[c] * grid.precondition;
+          }
         }
       }
     }
@@ -147,9 +196,9 @@ struct LevelK {
   }
 };
 
-template <int F, int NL>
+template <int F, int NL, int ND>
 __global__ __launch_bounds__(LevelCfg<F>::W * 64) void k_level(RcLevelKArgs a) {
-  using LK = LevelK<F, NL>;
+  using LK = LevelK<F, NL, ND>;
   constexpr int W = LK::W;
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
   float* wres = lds_dyn;
@@ -180,9 +229,9 @@ struct RcLevelRayKArgs {
 
 constexpr int kLvSampFloats = 5 * (kSlots + 3);
 
-template <int F, int NL, int S>
+template <int F, int NL, int S, int ND>
 __global__ __launch_bounds__(LevelCfg<F>::W * 64) void k_level_ray(RcLevelRayKArgs a) {
-  using LK = LevelK<F, NL>;
+  using LK = LevelK<F, NL, ND>;
   constexpr int W = LK::W;
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
   float* wres = lds_dyn;
@@ -223,51 +272,70 @@ bool level_prepare(K kernel, int lds, std::atomic<uint64_t>& prepared) {
   return (g_level_refused.load() & bit) == 0;
 }
 
-template <int F, int NL>
+template <int F, int NL, int ND>
 bool prepare_level() {
-  using LK = LevelK<F, NL>;
+  using LK = LevelK<F, NL, ND>;
   static std::atomic<uint64_t> prepared{0};
-  return level_prepare(&k_level<F, NL>, (LK::kResFloats + LK::W * kLvActSteps * 64) * (int)sizeof(float), prepared);
+  return level_prepare(&k_level<F, NL, ND>, (LK::kResFloats + LK::W * kLvActSteps * 64) * (int)sizeof(float), prepared);
 }
-template <int F, int NL, int S>
+template <int F, int NL, int S, int ND>
 bool prepare_level_ray() {
-  using LK = LevelK<F, NL>;
+  using LK = LevelK<F, NL, ND>;
   static std::atomic<uint64_t> prepared{0};
-  return level_prepare(&k_level_ray<F, NL, S>, (LK::kResFloats + LK::W * (kLvActSteps * 64 + kLvSampFloats)) * (int)sizeof(float), prepared);
+  return level_prepare(&k_level_ray<F, NL, S, ND>, (LK::kResFloats + LK::W * (kLvActSteps * 64 + kLvSampFloats)) * (int)sizeof(float), prepared);
 }
 
-template <int F, int NL>
+template <int F, int NL, int ND>
 void launch_level(const RcLevelKArgs& a, hipStream_t stream) {
-  using LK = LevelK<F, NL>;
+  using LK = LevelK<F, NL, ND>;
   constexpr int W = LK::W;
   const int lds = (LK::kResFloats + W * kLvActSteps * 64) * (int)sizeof(float);
-  (void)prepare_level<F, NL>();
+  (void)prepare_level<F, NL, ND>();
   const int cus = rc_device_cus();
   const int64_t tiles = (a.n + 31) / 32;
   const int64_t want = (tiles + W - 1) / W;
   dim3 grid((unsigned)(want < cus ? want : cus)), block(W * 64);
-  hipLaunchKernelGGL((k_level<F, NL>), grid, block, lds, stream, a);
+  hipLaunchKernelGGL((k_level<F, NL, ND>), grid, block, lds, stream, a);
 }
 
-template <int F, int NL, int S>
+template <int F, int NL, int S, int ND>
 void launch_level_ray(const RcLevelRayKArgs& a, hipStream_t stream) {
-  using LK = LevelK<F, NL>;
+  using LK = LevelK<F, NL, ND>;
   constexpr int W = LK::W;
   const int lds = (LK::kResFloats + W * (kLvActSteps * 64 + kLvSampFloats)) * (int)sizeof(float);
-  (void)prepare_level_ray<F, NL, S>();
+  (void)prepare_level_ray<F, NL, S, ND>();
   const int cus = rc_device_cus();
   const int64_t want = (a.sa.n_rays + W - 1) / W;
   dim3 grid((unsigned)(want < cus ? want : cus)), block(W * 64);
-  hipLaunchKernelGGL((k_level_ray<F, NL, S>), grid, block, lds, stream, a);
+  hipLaunchKernelGGL((k_level_ray<F, NL, S, ND>), grid, block, lds, stream, a);
+}
+
+// 3 when the grid has the reference's level layout -- levels [0, 3) dense, each with its cell table, the others hashed --
+// for which the F = 1 kernels have the compile-time form; -1 otherwise (any layout: kinds read from the level records)
+constexpr int kRefDense = 3;
+int level_layout(const RcGridDev& g) {
+  if (g.num_features != 1) return -1;
+  for (int l = 0; l < g.num_levels; ++l) {
+    const bool want_dense = l < kRefDense;
+    if ((g.lvl[l].dense != 0) != want_dense || (want_dense && !g.lvl[l].cell)) return -1;
+  }
+  return kRefDense;
 }
 
 }  // namespace
 
 // true when (F, number of levels) is one of the compiled shapes
 bool rc_level_supported(const RcGridDev& g) {
-  if (g.num_features == 1 && g.num_levels == 6) return prepare_level<1, 6>() && prepare_level_ray<1, 6, 64>();
-  if (g.num_features == 1 && g.num_levels == 7) return prepare_level<1, 7>() && prepare_level_ray<1, 7, 64>();
-  if (g.num_features == 4 && g.num_levels == 8) return prepare_level<4, 8>() && prepare_level_ray<4, 8, 32>();
+  // the level kernels compile the `hash & mask` form only (every table size the reference's configs use; other sizes take
+  // the separate gather kernel with its modulo)
+  for (int l = 0; l < g.num_levels; ++l)
+    if (!g.lvl[l].dense && g.lvl[l].mask == 0) return false;
+  const bool ref = level_layout(g) == kRefDense;
+  if (g.num_features == 1 && g.num_levels == 6)
+    return ref ? prepare_level<1, 6, kRefDense>() && prepare_level_ray<1, 6, 64, kRefDense>() : prepare_level<1, 6, -1>() && prepare_level_ray<1, 6, 64, -1>();
+  if (g.num_features == 1 && g.num_levels == 7)
+    return ref ? prepare_level<1, 7, kRefDense>() && prepare_level_ray<1, 7, 64, kRefDense>() : prepare_level<1, 7, -1>() && prepare_level_ray<1, 7, 64, -1>();
+  if (g.num_features == 4 && g.num_levels == 8) return prepare_level<4, 8, -1>() && prepare_level_ray<4, 8, 32, -1>();
   return false;
 }
 
@@ -284,9 +352,10 @@ void rc_launch_level_ray(const RcLevelArgs& A, const RcSampleArgs& sa, hipStream
   a.sa = sa;
   a.us = make_uspec(sa.S, sa.jitter != nullptr);
   a.y_max = sa.raydist_p < 0.0f ? nextafterf((sa.raydist_p - 1.0f) / sa.raydist_p, -INFINITY) : 0.0f;      // as rc_launch_sample
-  if (a.lv.grid.num_features == 1 && a.lv.grid.num_levels == 6) launch_level_ray<1, 6, 64>(a, stream);
-  else if (a.lv.grid.num_features == 1 && a.lv.grid.num_levels == 7) launch_level_ray<1, 7, 64>(a, stream);
-  else if (a.lv.grid.num_features == 4 && a.lv.grid.num_levels == 8) launch_level_ray<4, 8, 32>(a, stream);
+  const bool ref = level_layout(a.lv.grid) == kRefDense;
+  if (a.lv.grid.num_features == 1 && a.lv.grid.num_levels == 6) { if (ref) launch_level_ray<1, 6, 64, kRefDense>(a, stream); else launch_level_ray<1, 6, 64, -1>(a, stream); }
+  else if (a.lv.grid.num_features == 1 && a.lv.grid.num_levels == 7) { if (ref) launch_level_ray<1, 7, 64, kRefDense>(a, stream); else launch_level_ray<1, 7, 64, -1>(a, stream); }
+  else if (a.lv.grid.num_features == 4 && a.lv.grid.num_levels == 8) launch_level_ray<4, 8, 32, -1>(a, stream);
 }
 
 void rc_launch_level(const RcLevelArgs& A, hipStream_t stream) {
@@ -294,7 +363,8 @@ void rc_launch_level(const RcLevelArgs& A, hipStream_t stream) {
   RcLevelKArgs a{};
   a.grid = *A.grid; a.means = A.means; a.n = A.n; a.wstream = A.wstream;
   a.density_bias = A.density_bias; a.contract_radius = A.contract_radius; a.density = A.density;
-  if (a.grid.num_features == 1 && a.grid.num_levels == 6) launch_level<1, 6>(a, stream);
-  else if (a.grid.num_features == 1 && a.grid.num_levels == 7) launch_level<1, 7>(a, stream);
-  else if (a.grid.num_features == 4 && a.grid.num_levels == 8) launch_level<4, 8>(a, stream);
+  const bool ref = level_layout(a.grid) == kRefDense;
+  if (a.grid.num_features == 1 && a.grid.num_levels == 6) { if (ref) launch_level<1, 6, kRefDense>(a, stream); else launch_level<1, 6, -1>(a, stream); }
+  else if (a.grid.num_features == 1 && a.grid.num_levels == 7) { if (ref) launch_level<1, 7, kRefDense>(a, stream); else launch_level<1, 7, -1>(a, stream); }
+  else if (a.grid.num_features == 4 && a.grid.num_levels == 8) launch_level<4, 8, -1>(a, stream);
 }
