@@ -1178,13 +1178,22 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     src = (const int32_t*)W(h, "src_idx");
   }
   const int64_t nsh = resample ? n : np2;
+  bool pair_lookup = false;
   if (lean) {
     // density MLP of the last level once more, on the picked samples only (same kernel, same per-point arithmetic:
     // bitwise the values the full pass would have stored), compact outputs
     const int l2 = NL - 1;
     const int K2 = h->grids[l2].dev.num_levels * h->grids[l2].dev.num_features;
-    rc_launch_hashgrid_src(h->grids[l2].dev, W(h, "means" + LL), 1, src, np2, n, W(h, "feat_sel"), 1, n, c.contract_radius,
-                           nullptr, st);
+    // with the fused plan's interleaved tables at hand: this lookup and the appearance lookup below in one pass
+    pair_lookup = h->fused_ok && l2 == 2 && nsh == n && h->fused_mode != 0;
+    if (pair_lookup) {
+      RcPairTables pt{};
+      for (int l = 0; l < h->grids[2].dev.num_levels; ++l) pt.t[l] = h->fused_tmpl.pair_table[l];
+      rc_launch_hashgrid_pair(h->grids[2].dev, pt, W(h, "means" + LL), src, np2, n, W(h, "feat_sel"), W(h, "app"), n, c.contract_radius, st);
+    } else {
+      rc_launch_hashgrid_src(h->grids[l2].dev, W(h, "means" + LL), 1, src, np2, n, W(h, "feat_sel"), 1, n, c.contract_radius,
+                             nullptr, st);
+    }
     RcDensityMlpArgs ds{};
     ds.feat = W(h, "feat_sel"); ds.n = n; ds.ld = n; ds.K = K2; ds.wstream = h->packs["dens_" + LL].p;
     ds.means = W(h, "means" + LL); ds.src = src; ds.n_src = np2;
@@ -1193,8 +1202,9 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     rc_launch_density_mlp(ds, st);
   }
   stage_mark(h, slot, ST_GRID_APP, st);
-  rc_launch_hashgrid_src(h->grids[3].dev, W(h, "means" + LL), 1, src, np2, nsh, W(h, "app"), 1, nsh,
-                         c.contract_radius, nullptr, st);
+  if (!pair_lookup)
+    rc_launch_hashgrid_src(h->grids[3].dev, W(h, "means" + LL), 1, src, np2, nsh, W(h, "app"), 1, nsh,
+                           c.contract_radius, nullptr, st);
   if (A.tout) {
     enqueue_transient_tail(h, A, st);
     return;

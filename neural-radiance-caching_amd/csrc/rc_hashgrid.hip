@@ -66,6 +66,33 @@ __global__ __launch_bounds__(256) void k_hashgrid_fwd(RcGridDev g, const float* 
   }
 }
 
+// Two F = 4 grids of identical level geometry looked up at the same points in ONE pass over their interleaved tables
+// (rc_api.hip build_fused_tables: hashed levels [density 16 B | appearance 16 B] per entry, dense levels as cell tables
+// of such pairs): lanes j and j + 32 of a wave take the two halves of every pair of point j, so one 32-byte read serves
+// both grids -- half the sector requests of two k_hashgrid_fwd<4> passes (the picked samples of the resampling pass:
+// density grid of the last level + appearance grid).  Same index, weights and corner order: bitwise the same features.
+__global__ __launch_bounds__(256) void k_hashgrid_pair(RcGridDev g, RcPairTables pt, const float* __restrict__ pts,
+                                                         const int32_t* __restrict__ src, int64_t n_src, int64_t n,
+                                                         float* __restrict__ out_a, float* __restrict__ out_b, int64_t ldo,
+                                                         float contract_radius) {
+  const int lane = threadIdx.x & 63, j = lane & 31, which = lane >> 5;
+  const int64_t p = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + j;
+  const int l = blockIdx.y;
+  if (p >= n) return;
+  const int64_t q = src ? (int64_t)src[p] : p;
+  float x = pts[q], y = pts[n_src + q], z = pts[2 * n_src + q];
+  if (contract_radius > 0.0f) contract3(x, y, z, contract_radius);
+  const RcGridLevel L = g.lvl[l];
+  Corners<4> C;
+  grid_fetch<4, true, 2, true>(pt.t[l] + 4 * which, L.size, L.mask, 0u, L.dense != 0, unit_box(g.bbox, x), unit_box(g.bbox, y),
+                               unit_box(g.bbox, z), C);
+  float acc[4], jd[1];
+  grid_combine<4, false>(C, acc, jd);
+  float* out = which ? out_b : out_a;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) out[(int64_t)(l * 4 + f) * ldo + p] = acc[f] * g.precondition;
+}
+
 }  // namespace
 
 void rc_launch_hashgrid_src(const RcGridDev& g, const float* points, int soa_in, const int32_t* src, int64_t n_src,
@@ -96,4 +123,13 @@ void rc_launch_hashgrid(const RcGridDev& g, const float* points, int soa_in, int
                         hipStream_t stream) {
   rc_launch_hashgrid_src(g, points, soa_in, nullptr, n, n, out, feature_major, ldo, contract_radius, jac_out,
                          stream);
+}
+
+// g: the level geometry both grids share (fused_geometry_ok); feature-major outputs [L * 4][ldo]
+void rc_launch_hashgrid_pair(const RcGridDev& g, const RcPairTables& pt, const float* points_soa, const int32_t* src,
+                             int64_t n_src, int64_t n, float* out_a, float* out_b, int64_t ldo, float contract_radius,
+                             hipStream_t stream) {
+  if (n <= 0) return;
+  dim3 grid((unsigned)((n + 127) / 128), (unsigned)g.num_levels), block(256);
+  hipLaunchKernelGGL(k_hashgrid_pair, grid, block, 0, stream, g, pt, points_soa, src, n_src, n, out_a, out_b, ldo, contract_radius);
 }

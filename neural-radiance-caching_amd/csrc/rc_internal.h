@@ -46,6 +46,12 @@ struct RcGridDev {
 
 // points: world-space [n,3] (AoS) or SoA [3][n] (soa_in != 0).  Output feature-major [L*F][ldo]
 // (feature_major != 0) or row-major [n][L*F].  contract_radius <= 0 disables the contraction.
+// interleaved [grid A | grid B] tables of two F = 4 grids with the same level geometry, one per level (rc_api.hip
+// build_fused_tables)
+struct RcPairTables { const float* t[RC_MAX_GRID_LEVELS]; };
+void rc_launch_hashgrid_pair(const RcGridDev& g, const RcPairTables& pt, const float* points_soa, const int32_t* src,
+                             int64_t n_src, int64_t n, float* out_a, float* out_b, int64_t ldo, float contract_radius,
+                             hipStream_t stream);
 void rc_launch_hashgrid(const RcGridDev& g, const float* points, int soa_in, int64_t n, float* out,
                         int feature_major, int64_t ldo, float contract_radius, float* jac_out,
                         hipStream_t stream);

@@ -43,6 +43,9 @@ using namespace rcdev;
 namespace {
 
 constexpr int kLvActSteps = 33;
+#ifndef RC_LV4_GROUP
+#define RC_LV4_GROUP 4
+#endif
 
 template <int F> struct LevelCfg;
 template <> struct LevelCfg<1> { static constexpr int W = 12; };
@@ -116,65 +119,74 @@ struct LevelK {
     } else {
       // this half-wave's levels: l = 2 i + h (all their corner loads in flight before the first combine)
       constexpr int NH = (NL + 1) / 2;
-      Corners<F> C[NH];
+      // pairs whose loads are in flight together: all of them for F = 1; RC_LV4_GROUP of the four for F = 4 (128 registers
+      // of load destinations otherwise)
+      constexpr int GRP = F == 1 ? NH : RC_LV4_GROUP;
+      static_assert(NH % GRP == 0 || F == 1, "group size");
 #pragma unroll
-      for (int i = 0; i < NH; ++i) {
-        const int l = 2 * i + h;
-        if (l < NL) {
-          // Both level records of the pair (kernel arguments) into scalar registers, the half-wave's one selected in
-          // registers: indexing grid.lvl[] with the lane-dependent l makes every field a per-lane global load from the
-          // argument segment -- dependent round trips in front of the corner loads, and their s_waitcnt vmcnt(0) drains
-          // the previous pair's corners, so a lane never had more than one level in flight.  Kind of a level: 2 = dense
-          // with a cell table, 1 = dense, 0 = hashed (power-of-two tables only: rc_level_supported); a pair of one kind
-          // branches wave-uniformly, a mixed pair runs both sides under exec masks.
-          const RcGridLevel &L0 = grid.lvl[2 * i], &L1 = grid.lvl[2 * i + 1 < NL ? 2 * i + 1 : 2 * i];
-          const int size = pick_half(h, L0.size, L1.size);
-          const uint32_t mask = pick_half(h, L0.mask, L1.mask);
-          if constexpr (F == 1) {
-            const int k0 = L0.cell ? 2 : (L0.dense ? 1 : 0), k1 = L1.cell ? 2 : (L1.dense ? 1 : 0);
-            const float* tab = pick_half(h, k0 == 2 ? L0.cell : L0.table, k1 == 2 ? L1.cell : L1.table);
-            if (k0 == k1) {
-              if (k0 == 2) grid_fetch_cell(tab, size, ux, uy, uz, C[i]);
-              else grid_fetch<1, true>(tab, size, mask, 0u, k0 == 1, ux, uy, uz, C[i]);
-            } else if ((k0 == 1) | (k1 == 1)) {
-              grid_fetch<1, true>(pick_half(h, L0.table, L1.table), size, mask, 0u, pick_half(h, k0, k1) != 0, ux, uy, uz, C[i]);   // a dense level without its cell table in the pair: plain tables on both sides
-            } else {
-              grid_fetch<1, true, 1, true>(tab, size, mask, 0u, pick_half(h, k0, k1) == 2, ux, uy, uz, C[i]);
-            }
-          } else {
-            const bool d0 = L0.dense != 0, d1 = L1.dense != 0;
-            const float* tab = pick_half(h, L0.table, L1.table);
-            if (d0 == d1) grid_fetch<4, true>(tab, size, mask, 0u, d0, ux, uy, uz, C[i]);
-            else grid_fetch<4, true>(tab, size, mask, 0u, pick_half(h, d0, d1), ux, uy, uz, C[i]);
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (F == 1) {
-        // feature l of point j -> step l / 2, half l & 1 = h: this lane's own column
+      for (int i0 = 0; i0 < NH; i0 += GRP) {
+        Corners<F> C[GRP];
 #pragma unroll
-        for (int i = 0; i < KS0 - 1; ++i) {
-          const int l = 2 * i + h;
-          float v = 0.0f;
-          if (i < NH && l < NL) {
-            float f[1], jd[1];
-            grid_combine<1, false>(C[i < NH ? i : 0], f, jd);
-            v = f[0] * grid.precondition;
-          }
-          act[i * 64] = v;
-        }
-      } else {
-        // F = 4: feature 4 l + c -> step 2 l + c / 2, half c & 1
-#pragma unroll
-        for (int i = 0; i < NH; ++i) {
+        for (int ii = 0; ii < GRP; ++ii) {
+          const int i = i0 + ii;
           const int l = 2 * i + h;
           if (l < NL) {
-            float f[4], jd[1];
-            grid_combine<4, false>(C[i], f, jd);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) act_wave[(2 * l + (c >> 1)) * 64 + j + 32 * (c & 1)] = f[c] * grid.precondition;
+            // Both level records of the pair (kernel arguments) into scalar registers, the half-wave's one selected in
+            // registers: indexing grid.lvl[] with the lane-dependent l makes every field a per-lane global load from the
+            // argument segment -- dependent round trips in front of the corner loads, and their s_waitcnt vmcnt(0) drains
+            // the previous pair's corners, so a lane never had more than one level in flight.  Kind of a level: 2 = dense
+            // with a cell table, 1 = dense, 0 = hashed (power-of-two tables only: rc_level_supported); a pair of one kind
+            // branches wave-uniformly, a mixed pair runs both sides under exec masks.
+            const RcGridLevel &L0 = grid.lvl[2 * i], &L1 = grid.lvl[2 * i + 1 < NL ? 2 * i + 1 : 2 * i];
+            const int size = pick_half(h, L0.size, L1.size);
+            const uint32_t mask = pick_half(h, L0.mask, L1.mask);
+            if constexpr (F == 1) {
+              const int k0 = L0.cell ? 2 : (L0.dense ? 1 : 0), k1 = L1.cell ? 2 : (L1.dense ? 1 : 0);
+              const float* tab = pick_half(h, k0 == 2 ? L0.cell : L0.table, k1 == 2 ? L1.cell : L1.table);
+              if (k0 == k1) {
+                if (k0 == 2) grid_fetch_cell(tab, size, ux, uy, uz, C[ii]);
+                else grid_fetch<1, true>(tab, size, mask, 0u, k0 == 1, ux, uy, uz, C[ii]);
+              } else if ((k0 == 1) | (k1 == 1)) {
+                grid_fetch<1, true>(pick_half(h, L0.table, L1.table), size, mask, 0u, pick_half(h, k0, k1) != 0, ux, uy, uz, C[ii]);   // a dense level without its cell table in the pair: plain tables on both sides
+              } else {
+                grid_fetch<1, true, 1, true>(tab, size, mask, 0u, pick_half(h, k0, k1) == 2, ux, uy, uz, C[ii]);
+              }
+            } else {
+              const bool d0 = L0.dense != 0, d1 = L1.dense != 0;
+              const float* tab = pick_half(h, L0.table, L1.table);
+              if (d0 == d1) grid_fetch<4, true>(tab, size, mask, 0u, d0, ux, uy, uz, C[ii]);
+              else grid_fetch<4, true>(tab, size, mask, 0u, pick_half(h, d0, d1), ux, uy, uz, C[ii]);
+            }
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (F == 1) {
+          // feature l of point j -> step l / 2, half l & 1 = h: this lane's own column
+#pragma unroll
+          for (int i = 0; i < KS0 - 1; ++i) {
+            const int l = 2 * i + h;
+            float v = 0.0f;
+            if (i < NH && l < NL) {
+              float f[1], jd[1];
+              grid_combine<1, false>(C[i < NH ? i : 0], f, jd);
+              v = f[0] * grid.precondition;
+            }
+            act[i * 64] = v;
+          }
+        } else {
+          // F = 4: feature 4 l + c -> step 2 l + c / 2, half c & 1
+#pragma unroll
+          for (int ii = 0; ii < GRP; ++ii) {
+            const int l = 2 * (i0 + ii) + h;
+            if (l < NL) {
+              float f[4], jd[1];
+              grid_combine<4, false>(C[ii], f, jd);
+#pragma unroll
+              for (int c = 0; c < 4; ++c) act_wave[(2 * l + (c >> 1)) * 64 + j + 32 * (c & 1)] = f[c] * grid.precondition;
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     act[(KS0 - 1) * 64] = h == 0 ? 1.0f : 0.0f;
