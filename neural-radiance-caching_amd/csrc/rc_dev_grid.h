@@ -93,7 +93,8 @@ __device__ __forceinline__ uint32_t cell_index(int size, float x01, float y01, f
   const int M = size + 3;
   const int q0 = min(max(base[0], -1), size + 1) + 1, q1 = min(max(base[1], -1), size + 1) + 1,
             q2 = min(max(base[2], -1), size + 1) + 1;
-  return ((uint32_t)q2 * (uint32_t)M + (uint32_t)q1) * (uint32_t)M + (uint32_t)q0;
+  // 24-bit multiplies (full rate; v_mul_lo_u32 is a quarter-rate instruction): every operand is below 2^24
+  return __umul24(__umul24((uint32_t)q2, (uint32_t)M) + (uint32_t)q1, (uint32_t)M) + (uint32_t)q0;
 }
 
 // A dense F = 1 level through its cell table when the WHOLE WAVE is on such a level: a lane reads its 8 corners as two

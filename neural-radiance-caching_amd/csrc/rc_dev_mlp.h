@@ -191,6 +191,14 @@ __device__ __forceinline__ void mlp_layer_pt(const WS& w, const float* act, int 
   }
 }
 
+// max(x, 0) as ONE instruction.  fmaxf() on a value the compiler cannot prove canonical -- an MFMA result -- is preceded
+// by a canonicalising `v_max_f32 x, x, x`: two instructions per activation, 64 per 32-point tile of a proposal MLP.
+__device__ __forceinline__ float relu0(float x) {
+  float y;
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(y) : "v"(x));
+  return y;
+}
+
 // Park NT accumulator tiles as the next layer's activation steps [base, base + 16 NT).
 template <int NT, bool RELU>
 __device__ __forceinline__ void park(const f32x16 (&acc)[NT], float* act, int base) {
@@ -199,7 +207,7 @@ __device__ __forceinline__ void park(const f32x16 (&acc)[NT], float* act, int ba
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float v = acc[t][r];
-      act[(base + t * 16 + r) * 64] = RELU ? fmaxf(v, 0.0f) : v;
+      act[(base + t * 16 + r) * 64] = RELU ? relu0(v) : v;
     }
 }
 
@@ -228,7 +236,7 @@ __device__ __forceinline__ void dot_out(const WS& w, const f32x16 (&hid)[PT][NT]
         const float wv = ws_read<NF, W, CH>(w, FBASE + (o * NT + t) * 16 + r);
         if constexpr (KEEP) { if (o == 0) keep[t * 16 + r] = wv; }
 #pragma unroll
-        for (int p = 0; p < PT; ++p) part[p][o][r & 1] = __builtin_fmaf(fmaxf(hid[p][t][r], 0.0f), wv, part[p][o][r & 1]);
+        for (int p = 0; p < PT; ++p) part[p][o][r & 1] = __builtin_fmaf(relu0(hid[p][t][r]), wv, part[p][o][r & 1]);
       }
 #pragma unroll
   for (int o = 0; o < NO; ++o) {

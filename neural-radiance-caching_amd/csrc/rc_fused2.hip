@@ -130,7 +130,7 @@ __device__ __forceinline__ void park_n(const f32x16* acc, float* act, int base) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float v = acc[t][r];
-      act[(base + t * 16 + r) * 64] = RELU ? fmaxf(v, 0.0f) : v;
+      act[(base + t * 16 + r) * 64] = RELU ? relu0(v) : v;
     }
 }
 

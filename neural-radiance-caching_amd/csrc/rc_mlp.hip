@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hb[(t * 16 + r) * 64] = fmaxf(acc[t][r], 0.0f);
+      for (int r = 0; r < 16; ++r) hb[(t * 16 + r) * 64] = relu0(acc[t][r]);
   }
 
   float out[NO], wout[GRAD ? 32 : 1];

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_bwd(RcDensityBwdArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       m0 |= (acc[t][r] > 0.0f ? 1u : 0u) << (t * 16 + r);
-      row[t * 16 + r] = fmaxf(acc[t][r], 0.0f);
+      row[t * 16 + r] = relu0(acc[t][r]);
     }
   store_rows(a.a1, row);
   park<2, true>(acc, act, 0);
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_bwd(RcDensityBwdArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       m1 |= (acc[t][r] > 0.0f ? 1u : 0u) << (t * 16 + r);
-      row[t * 16 + r] = fmaxf(acc[t][r], 0.0f);
+      row[t * 16 + r] = relu0(acc[t][r]);
     }
   store_rows(a.a2, row);
 

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_shader(RcTransShaderA
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a.irr_feat[(tile * 32 + t * 16 + r) * 64 + lane] = fmaxf(ir[t][r], 0.0f);
+        for (int r = 0; r < 16; ++r) a.irr_feat[(tile * 32 + t * 16 + r) * 64 + lane] = relu0(ir[t][r]);
     }
   }
   const float rough = softplus(hd[0][0] + a.roughness_bias);                   // nerf.py:633-634
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_shader(RcTransShaderA
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a.slf_feat[(tile * 64 + t * 16 + r) * 64 + lane] = fmaxf(skip[t][r], 0.0f);
+        for (int r = 0; r < 16; ++r) a.slf_feat[(tile * 64 + t * 16 + r) * 64 + lane] = relu0(skip[t][r]);
     }
   }
   if (valid && tile_ok && h == 0) {
