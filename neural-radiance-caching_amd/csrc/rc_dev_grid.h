@@ -25,6 +25,7 @@ template <class T>
 __device__ __forceinline__ T pick_half(int half, T first, T second) { return half ? second : first; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int F> struct Vec;
 template <> struct Vec<1> { float v[1]; };
@@ -284,16 +285,35 @@ __device__ __forceinline__ void grid_combine(const Corners<F>& C, float (&acc)[F
 #pragma unroll
   for (int f = 0; f < F; ++f) acc[f] = 0.0f;
   float v[8][F];
+  if constexpr (F == 4) {
+    // the four features as two register pairs: packed multiplies and adds (v_pk_mul_f32 / v_pk_add_f32, two lanes of
+    // fp32 per instruction, the same separate roundings per element)
+    f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const int b0 = (c >> 2) & 1, b1 = (c >> 1) & 1, b2 = c & 1;
-    const float w0 = b0 ? C.cw[0] : fw[0], w1 = b1 ? C.cw[1] : fw[1], w2 = b2 ? C.cw[2] : fw[2];
-    const float w = (w0 * w1) * w2;
-    const bool zero = (C.zero_mask >> c) & 1u;
+    for (int c = 0; c < 8; ++c) {
+      const int b0 = (c >> 2) & 1, b1 = (c >> 1) & 1, b2 = c & 1;
+      const float w0 = b0 ? C.cw[0] : fw[0], w1 = b1 ? C.cw[1] : fw[1], w2 = b2 ? C.cw[2] : fw[2];
+      const float w = (w0 * w1) * w2;
+      const bool zero = (C.zero_mask >> c) & 1u;
 #pragma unroll
-    for (int f = 0; f < F; ++f) v[c][f] = zero ? 0.0f : C.val[c].v[f];
+      for (int f = 0; f < 4; ++f) v[c][f] = zero ? 0.0f : C.val[c].v[f];
+      const f32x2 vlo = {v[c][0], v[c][1]}, vhi = {v[c][2], v[c][3]}, ww = {w, w};
+      lo = lo + vlo * ww;
+      hi = hi + vhi * ww;
+    }
+    acc[0] = lo.x; acc[1] = lo.y; acc[2] = hi.x; acc[3] = hi.y;
+  } else {
 #pragma unroll
-    for (int f = 0; f < F; ++f) acc[f] = acc[f] + v[c][f] * w;
+    for (int c = 0; c < 8; ++c) {
+      const int b0 = (c >> 2) & 1, b1 = (c >> 1) & 1, b2 = c & 1;
+      const float w0 = b0 ? C.cw[0] : fw[0], w1 = b1 ? C.cw[1] : fw[1], w2 = b2 ? C.cw[2] : fw[2];
+      const float w = (w0 * w1) * w2;
+      const bool zero = (C.zero_mask >> c) & 1u;
+#pragma unroll
+      for (int f = 0; f < F; ++f) v[c][f] = zero ? 0.0f : C.val[c].v[f];
+#pragma unroll
+      for (int f = 0; f < F; ++f) acc[f] = acc[f] + v[c][f] * w;
+    }
   }
   if constexpr (JAC) {
     // d feature / d loc_a = sum over the 4 corner pairs along axis a of (product of the two other axes' weights) x
@@ -306,6 +326,27 @@ __device__ __forceinline__ void grid_combine(const Corners<F>& C, float (&acc)[F
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int k = 0; k < 2; ++k) { p12[i][k] = w1s[i] * w2s[k]; p02[i][k] = w0s[i] * w2s[k]; p01[i][k] = w0s[i] * w1s[k]; }
+    if constexpr (F == 4) {
+      // packed over feature pairs as above (v_pk_add_f32 with a negated operand, v_pk_fma_f32)
+#pragma unroll
+      for (int fp = 0; fp < 2; ++fp) {
+        f32x2 vv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) vv[c] = f32x2{v[c][2 * fp], v[c][2 * fp + 1]};
+        f32x2 g0 = {0.0f, 0.0f}, g1 = {0.0f, 0.0f}, g2 = {0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            g0 = __builtin_elementwise_fma(vv[4 + 2 * i + k] - vv[2 * i + k], f32x2{p12[i][k], p12[i][k]}, g0);
+            g1 = __builtin_elementwise_fma(vv[4 * i + 2 + k] - vv[4 * i + k], f32x2{p02[i][k], p02[i][k]}, g1);
+            g2 = __builtin_elementwise_fma(vv[4 * i + 2 * k + 1] - vv[4 * i + 2 * k], f32x2{p01[i][k], p01[i][k]}, g2);
+          }
+        jacc[0 * F + 2 * fp] = g0.x; jacc[0 * F + 2 * fp + 1] = g0.y;
+        jacc[1 * F + 2 * fp] = g1.x; jacc[1 * F + 2 * fp + 1] = g1.y;
+        jacc[2 * F + 2 * fp] = g2.x; jacc[2 * F + 2 * fp + 1] = g2.y;
+      }
+    } else
 #pragma unroll
     for (int f = 0; f < F; ++f) {
       float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;

@@ -43,12 +43,15 @@ using namespace rcdev;
 namespace {
 
 constexpr int kLvActSteps = 33;
+#ifndef RC_LV1_WAVES
+#define RC_LV1_WAVES 12
+#endif
 #ifndef RC_LV4_GROUP
 #define RC_LV4_GROUP 4
 #endif
 
 template <int F> struct LevelCfg;
-template <> struct LevelCfg<1> { static constexpr int W = 12; };
+template <> struct LevelCfg<1> { static constexpr int W = RC_LV1_WAVES; };
 template <> struct LevelCfg<4> { static constexpr int W = 8; };
 
 struct RcLevelKArgs {
@@ -70,7 +73,7 @@ struct LevelK {
   static constexpr int K = F * NL, KS0 = (K + 1) / 2 + 1;
   static constexpr int NOB = KS0 == 17 ? 4 : 1;                            // rows the output layer was packed with
   static constexpr int F_D0 = 0, F_D1 = 2 * KS0, F_DO = 2 * KS0 + 66, NF = F_DO + NOB * 33;
-  static constexpr int CH = 288;   // > NF and a multiple of 4 W (ws_issue is instantiated, never run): the whole stream is one resident chunk
+  static constexpr int CH = (NF / (4 * W) + 1) * 4 * W;   // > NF and a multiple of 4 W (ws_issue is instantiated, never run): the whole stream is one resident chunk
   static_assert(NF <= CH && CH % (4 * W) == 0, "stream must fit the resident chunk");
   static constexpr int kResFloats = ((NF + 3) / 4) * 4 * 64;               // [NF padded to 4][64]
 
@@ -240,6 +243,7 @@ struct RcLevelRayKArgs {
 };
 
 constexpr int kLvSampFloats = 5 * (kSlots + 3);
+static_assert(kLvSampFloats <= kLvActSteps * 64, "sampler scratch must fit the activation slice");
 
 template <int F, int NL, int S, int ND>
 __global__ __launch_bounds__(LevelCfg<F>::W * 64) void k_level_ray(RcLevelRayKArgs a) {
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(LevelCfg<F>::W * 64) void k_level_ray(RcLevelRayKAr
   float* wres = lds_dyn;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* act_wave = lds_dyn + LK::kResFloats + wave * (kLvActSteps * 64);
-  float* samp = lds_dyn + LK::kResFloats + W * (kLvActSteps * 64) + wave * kLvSampFloats;
+  float* samp = act_wave;      // the sampler's step functions live in the wave's activation slice: it is done before the first tile writes there
   LK::load_weights(a.lv.wstream, wres, wave, lane);
   WStream ws{a.lv.wstream, wres, lane, wave};
   const int j = lane & 31, h = lane >> 5;
@@ -294,7 +298,7 @@ template <int F, int NL, int S, int ND>
 bool prepare_level_ray() {
   using LK = LevelK<F, NL, ND>;
   static std::atomic<uint64_t> prepared{0};
-  return level_prepare(&k_level_ray<F, NL, S, ND>, (LK::kResFloats + LK::W * (kLvActSteps * 64 + kLvSampFloats)) * (int)sizeof(float), prepared);
+  return level_prepare(&k_level_ray<F, NL, S, ND>, (LK::kResFloats + LK::W * (kLvActSteps * 64)) * (int)sizeof(float), prepared);
 }
 
 template <int F, int NL, int ND>
@@ -314,7 +318,7 @@ template <int F, int NL, int S, int ND>
 void launch_level_ray(const RcLevelRayKArgs& a, hipStream_t stream) {
   using LK = LevelK<F, NL, ND>;
   constexpr int W = LK::W;
-  const int lds = (LK::kResFloats + W * (kLvActSteps * 64 + kLvSampFloats)) * (int)sizeof(float);
+  const int lds = (LK::kResFloats + W * (kLvActSteps * 64)) * (int)sizeof(float);
   (void)prepare_level_ray<F, NL, S, ND>();
   const int cus = rc_device_cus();
   const int64_t want = (a.sa.n_rays + W - 1) / W;
