@@ -1042,7 +1042,7 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     for (int l = 0; l < 3; ++l) F.jitter[l] = rnd ? rnd->jitter[l] : nullptr;
     F.out = A.out;
     F.direct = h->fused_direct;
-    F.team = (h->fused_mode == 1 && !A.export_samples) ? 1 : 0;          // mode 3: the one-wavefront-per-ray form
+    F.team = h->fused_mode == 1 ? 1 : 0;          // mode 3: the one-wavefront-per-ray form
     F.stagger_cycles = h->fused_stagger;
     F.prio_mode = h->fused_prio;
     if (A.export_samples) {

@@ -572,7 +572,9 @@ void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream) {
     else hipLaunchKernelGGL((k_cache_fused<false, true>), grid, block, lds, stream, a);
     return;
   }
-  if (L.export_samples) {
+  if (L.export_samples && L.team) {
+    a.f_tdist = L.f_tdist; a.f_density = L.f_density; a.f_means = L.f_means; a.f_normals_pred = L.f_normals_pred;
+  } else if (L.export_samples) {
     a.f_tdist = L.f_tdist; a.f_density = L.f_density; a.f_means = L.f_means; a.f_normals_pred = L.f_normals_pred;
     if (L.out.ptr[RC_OUT_NORMALS]) hipLaunchKernelGGL((k_cache_fused<true, false, false, true>), grid, block, lds, stream, a);
     else hipLaunchKernelGGL((k_cache_fused<false, false, false, true>), grid, block, lds, stream, a);

@@ -449,6 +449,17 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
     density = density_of(out[0], cx, cy, cz, a.grid[2].bbox);
     npx = out[1]; npy = out[2]; npz = out[3];
     neg_normalize(npx, npy, npz);
+    // export (the material stage's primary pass picks its shading point from these): fence posts, density, sample means
+    // and predicted normals of the last level into the workspace, as rc_fused.hip's EXPORT instantiation leaves them
+    if (a.f_density && q == 0 && ray_ok) {
+      const int64_t np = a.n * 32, p = ray * 32 + j;
+      for (int e2 = lane; e2 <= 32; e2 += 64) a.f_tdist[ray * 33 + e2] = s_td[e2];
+      if (h == 0) {
+        a.f_density[p] = density;
+        a.f_means[p] = mx; a.f_means[np + p] = my; a.f_means[2 * np + p] = mz;
+        a.f_normals_pred[p] = npx; a.f_normals_pred[np + p] = npy; a.f_normals_pred[2 * np + p] = npz;
+      }
+    }
     if constexpr (GRAD) {
       // the backward pass borrows [0, 32): every wave keeps its half of the hidden feature in registers meanwhile
       float hid[16];
