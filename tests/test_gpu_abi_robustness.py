@@ -180,9 +180,9 @@ def test_level_kernels_equal_the_separate_gather_and_mlp_kernels(n):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 3, 130, 257, 768])
 def test_material_stage_is_bitwise_the_same_on_every_launch_plan(n):
-    """rc_render_material on the three launch plans of rc_set_fused: 1 (default) runs the primary cache pass as the ONE
-    fused launch with its per-sample results exported for the shading-point pick, 2 the launch-per-stage pass with the
-    level kernels, 0 one kernel per stage.  Every cache and material output, the picks and the secondary radiance are
+    """rc_render_material on the launch plans of rc_set_fused: 1 (default) runs the primary cache pass as the ONE fused
+    launch (two wavefronts per ray) with its per-sample results exported for the shading-point pick, 3 the same on the
+    one-wavefront-per-ray kernel, 2 the launch-per-stage pass with the level kernels, 0 one kernel per stage.  Every cache and material output, the picks and the secondary radiance are
     bitwise equal.  (768 primary rays = 24 576 secondary rays: from there on plan 1 runs a proposal level of the trace
     with its sampling in front as ONE launch, one ray per wave -- k_level_ray.)"""
     from oracle import material_ref
@@ -193,7 +193,7 @@ def test_material_stage_is_bitwise_the_same_on_every_launch_plan(n):
     rays = nrc_amd.synthetic_rays(n, seed=5)
     rnd = material_ref.draw_randoms(cfg, n, seed=8)
     res = {}
-    for mode in (0, 2, 1):
+    for mode in (0, 2, 3, 1):
         rc.set_fused(mode)
         cres, mres = rc.render_material(rays.hot_fields(), rnd)
         torch.cuda.synchronize()
@@ -203,7 +203,7 @@ def test_material_stage_is_bitwise_the_same_on_every_launch_plan(n):
         res[mode]["s:inds"] = torch.from_numpy(rc.workspace("s:inds", np.int32)[: n * 32].copy())
         res[mode]["sec_rgb"] = torch.from_numpy(rc.workspace("sec_rgb")[: n * 96].copy())
         res[mode]["weights2"] = torch.from_numpy(rc.workspace("weights2")[: n * 32].copy())
-    for mode in (2, 1):
+    for mode in (2, 3, 1):
         for k in res[0]:
             assert torch.equal(res[0][k].cpu(), res[mode][k].cpu()), (mode, k)
 
