@@ -34,6 +34,11 @@
 // Copies of the hashed F = 1 tables with the two x-corners of a cell adjacent (one 8-byte load for 15 of 16 lanes with
 // four copies) were built, bitwise equal, and measured slower (+26 / +100 us): they multiply the footprint the L2 sees,
 // and the number of L1 lookups was not the bound.
+// Round 3: the lookup as the generated code really ran it had ONE level in flight per lane -- `grid.lvl[2 i + h]` with the
+// lane-dependent h made every field of the level record a per-lane load from the argument segment, each behind an
+// s_waitcnt vmcnt(0).  Rebuilt (tile() below, rc_dev_grid.h pair_fetch): level records as scalars, compile-time level
+// kinds for the reference's layout (ND), the loads of a level pair split by corner between the half-waves.  The F = 1
+// levels of the trace: 314 -> 284, 458 -> 415 us (NOT bitwise-affecting: same features, same order).
 #include "rc_dev_grid.h"
 #include "rc_dev_mlp.h"
 #include "rc_dev_sample.h"
