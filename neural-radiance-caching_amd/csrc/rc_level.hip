@@ -39,6 +39,7 @@
 // s_waitcnt vmcnt(0).  Rebuilt (tile() below, rc_dev_grid.h pair_fetch): level records as scalars, compile-time level
 // kinds for the reference's layout (ND), the loads of a level pair split by corner between the half-waves.  The F = 1
 // levels of the trace: 314 -> 284, 458 -> 415 us (NOT bitwise-affecting: same features, same order).
+#include <stdlib.h>
 #include "rc_dev_grid.h"
 #include "rc_dev_mlp.h"
 #include "rc_dev_sample.h"
@@ -336,6 +337,7 @@ void launch_level_ray(const RcLevelRayKArgs& a, hipStream_t stream) {
 constexpr int kRefDense = 3;
 int level_layout(const RcGridDev& g) {
   if (g.num_features != 1) return -1;
+  if (const char* e = getenv("RC_LEVEL_ANY_LAYOUT")) { if (e[0] == '1') return -1; }      // tests: force the run-time form
   for (int l = 0; l < g.num_levels; ++l) {
     const bool want_dense = l < kRefDense;
     if ((g.lvl[l].dense != 0) != want_dense || (want_dense && !g.lvl[l].cell)) return -1;

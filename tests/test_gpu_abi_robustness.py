@@ -236,3 +236,36 @@ def test_level_kernel_with_its_sampling_in_front_equals_the_separate_kernels():
             for k in res[0]:
                 assert torch.equal(res[0][k].cpu(), res[mode][k].cpu()), (mask, mode, k)
     rc.set_fused(1)
+
+
+@pytest.mark.gpu
+def test_level_kernels_run_time_layout_form_equals_the_compile_time_form(monkeypatch):
+    """rc_level.hip has two forms of the F = 1 level lookup: kinds of the grid levels compile-time for the reference's
+    layout (three dense levels with cell tables, then hashed ones; loads of a level pair split by corner between the
+    half-waves) and read from the level records for any other layout.  RC_LEVEL_ANY_LAYOUT=1 makes the launcher pick the
+    second on the reference's layout too: same densities, same outputs, bit for bit (k_level behind k_sample_level on
+    plan 2, k_level_ray on plan 1 from 24 576 rays on)."""
+    from nrc_amd import rc_ext
+    rc = common.make_rc()
+    rc.set_graph_mode(0)
+    n = 24577
+    rays = nrc_amd.synthetic_rays(n, seed=77).hot_fields()
+    rnd = {"jitter": common.jitters(n, seed=9), "gumbel": np.random.default_rng(3).gumbel(size=(n, 32)).astype(np.float32)}
+    mask = rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_RESAMPLE
+    res = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("RC_LEVEL_ANY_LAYOUT", form)
+        for mode in (2, 1):
+            rc.set_fused(mode)
+            o = rc.render_rays(rays, rnd, mask, outputs=["rgb", "acc"])
+            torch.cuda.synchronize()
+            r = {k: v.clone() for k, v in o.items()}
+            for nm, cnt in (("density0", n * 64), ("density1", n * 64), ("density2", n * 32)):
+                r[nm] = torch.from_numpy(rc.workspace(nm)[:cnt].copy())
+            res[(form, mode)] = r
+    monkeypatch.delenv("RC_LEVEL_ANY_LAYOUT")
+    rc.set_fused(1)
+    for mode in (2, 1):
+        for k in res[("0", mode)]:
+            assert torch.equal(res[("0", mode)][k].cpu(), res[("1", mode)][k].cpu()), (mode, k)
+    assert float(res[("0", 1)]["density0"].abs().sum()) > 0.0
