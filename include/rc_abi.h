@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 3
+#define RC_ABI_VERSION 4
 #define RC_MAX_LEVELS 3
 
 typedef struct rc_handle rc_handle;
@@ -229,6 +229,15 @@ int rc_load_weights(rc_handle* h, const rc_tensor_desc* descs, int32_t n);
  * (BaseMaterialModel.__call__ -> BaseNeRFModel.__call__, internal/models.py:1144-1254, 657-774). */
 int rc_render_rays(rc_handle* h, const rc_rays* rays, int64_t n_rays, const rc_randoms* rnd,
                    uint32_t pass_mask, const rc_outputs* out, void* stream);
+
+/* -- the chunk loop of models.render_image (internal/models.py:2412-2514) for passes that need no random inputs:
+ * n_chunks consecutive batches of `chunk` rays out of the arrays `rays` points to (the caller has edge-padded the last
+ * one: utils.shard / np.pad(mode="edge"), internal/utils.py:333-343, models.py:2437-2441), chunk i enqueued on
+ * streams[i % n_streams] with its outputs at out0->ptr[k] + i * out_stride floats (k over the requested outputs).
+ * Exactly n_chunks calls of rc_render_rays(rnd = NULL) -- same kernels, same results, same stream semantics per chunk --
+ * without a trip through the caller's language per chunk.  (ABI v4.) */
+int rc_render_chunks(rc_handle* h, const rc_rays* rays, int64_t chunk, int64_t n_chunks, uint32_t pass_mask,
+                     const rc_outputs* out0, int64_t out_stride, void* const* streams, int32_t n_streams);
 
 /* -- model.apply(..., passes=("cache","light","material")) for the material stage: the cache pass on the
  * primary rays (-> cache_out, the `cache_<k>` keys), one resampled shading point per ray, light sampler,

@@ -1425,6 +1425,29 @@ int rc_allgather_outputs(rc_handle* h, void* nccl_comm, const rc_outputs* local,
   RC_CATCH(h)
 }
 
+// The chunk loop of render_image in native code: n_chunks x rc_render_rays on alternating streams (include/rc_abi.h).
+int rc_render_chunks(rc_handle* h, const rc_rays* rays, int64_t chunk, int64_t n_chunks, uint32_t pass_mask,
+                     const rc_outputs* out0, int64_t out_stride, void* const* streams, int32_t n_streams) {
+  if (!h) return RC_ERR_INVALID_ARG;
+  if (!rays || !out0 || !streams) return fail(h, RC_ERR_INVALID_ARG, "rc_render_chunks: null rays/outputs/streams");
+  if (chunk <= 0 || n_chunks < 0 || n_streams <= 0 || out_stride < 0)
+    return fail(h, RC_ERR_INVALID_ARG, "rc_render_chunks: chunk, n_chunks, n_streams, out_stride out of range");
+  if ((pass_mask & RC_PASS_SECONDARY) || (pass_mask & RC_PASS_RESAMPLE))
+    return fail(h, RC_ERR_UNSUPPORTED, "rc_render_chunks: passes that draw random numbers go through rc_render_rays per chunk");
+  for (int64_t i = 0; i < n_chunks; ++i) {
+    rc_rays r = *rays;
+    const int64_t o = i * chunk;
+    auto adv = [&](const float*& p, int w) { if (p) p += o * w; };
+    adv(r.origins, 3); adv(r.directions, 3); adv(r.viewdirs, 3); adv(r.near, 1); adv(r.far, 1); adv(r.lights, 3); adv(r.normals, 3);
+    rc_outputs out = *out0;
+    for (int k = 0; k < RC_OUT_COUNT; ++k)
+      if (out.ptr[k]) out.ptr[k] += i * out_stride;
+    const int rc = rc_render_rays(h, &r, chunk, nullptr, pass_mask, &out, streams[i % n_streams]);
+    if (rc) return rc;
+  }
+  return RC_OK;
+}
+
 int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_randoms* rnd,
                        const rc_material_randoms* mr, int32_t K, const rc_outputs* cache_out,
                        const rc_mat_outputs* mat_out, void* stream_v) {

@@ -726,13 +726,15 @@ def _render_image_device(render_fn, dev, rng, rays, config, passes, verbose, res
           rc_plan, layout = mdl._plan(chunk, False, "lossmult" in names)
           mdl._ensure_variables(getattr(render_fn, "variables", None))
           handles = [s_.cuda_stream for s_ in pool]
+          # the loop over the chunks itself runs in the library (rc_render_chunks: chunk i on stream i % 2, outputs into
+          # row i of the arena); what is left per chunk here is the bookkeeping of the sink
+          full = {k: getattr(drays, k) for k in hot if k != "lossmult"}
+          mdl.rc.render_chunks(full, chunk, n_chunks, rc_ext.RC_PASS_CACHE, rc_plan, arena, handles)
           for i_chunk in range(n_chunks):
               if verbose and i_chunk % max(1, n_chunks // 10) == 0:
                   print(f"Rendering chunk {i_chunk}/{n_chunks-1}")
-              fields = {k: cols[k][i_chunk][0] for k in hot}
               row = arena[i_chunk]
-              mdl.rc.render_chunk(fields, None, rc_ext.RC_PASS_CACHE, rc_plan, row, handles[i_chunk % len(pool)])
-              extras = (fields["lossmult"].reshape(-1, 1).expand(-1, 3),) if "lossmult" in fields else ()
+              extras = (cols["lossmult"][i_chunk][0].reshape(-1, 1).expand(-1, 3),) if "lossmult" in hot else ()
               sink.add_flat(RenderDict(row, layout, mdl._consts, extras))
       for i_chunk in range(0 if not direct else n_chunks, n_chunks):
           if verbose and i_chunk % max(1, n_chunks // 10) == 0:

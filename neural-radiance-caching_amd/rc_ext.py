@@ -14,7 +14,7 @@ import numpy as np
 
 from .config import GridConfig, RenderConfig
 
-RC_ABI_VERSION = 3
+RC_ABI_VERSION = 4
 RC_MAX_LEVELS = 3
 
 RC_PASS_CACHE = 0x1
@@ -146,7 +146,7 @@ class rc_cast_outputs(C.Structure):
 
 
 EXPORTS = (
-    "rc_create", "rc_destroy", "rc_last_error", "rc_abi_version", "rc_load_weights", "rc_render_rays",
+    "rc_create", "rc_destroy", "rc_last_error", "rc_abi_version", "rc_load_weights", "rc_render_rays", "rc_render_chunks",
     "rc_hashgrid_lookup", "rc_sample_intervals", "rc_workspace_ptr", "rc_set_profiling", "rc_stage_count",
     "rc_stage_name", "rc_stage_times_ms", "rc_set_graph_mode", "rc_set_fused", "rc_render_material", "rc_set_transient", "rc_render_transient", "rc_cast_rays",
     "rc_prng_fill", "rc_density_grad_size", "rc_density_grad_layout", "rc_density_backward",
@@ -200,6 +200,9 @@ def load_library():
     lib.rc_render_rays.argtypes = [C.c_void_p, C.POINTER(rc_rays), C.c_int64, C.POINTER(rc_randoms), C.c_uint32,
                                    C.POINTER(rc_outputs), C.c_void_p]
     lib.rc_render_rays.restype = C.c_int
+    lib.rc_render_chunks.argtypes = [C.c_void_p, C.POINTER(rc_rays), C.c_int64, C.c_int64, C.c_uint32,
+                                     C.POINTER(rc_outputs), C.c_int64, C.POINTER(C.c_void_p), C.c_int32]
+    lib.rc_render_chunks.restype = C.c_int
     lib.rc_render_material.argtypes = [C.c_void_p, C.POINTER(rc_rays), C.c_int64, C.POINTER(rc_randoms),
                                        C.POINTER(rc_material_randoms), C.c_int32, C.POINTER(rc_outputs),
                                        C.POINTER(rc_mat_outputs), C.c_void_p]
@@ -499,6 +502,33 @@ class RadianceCache:
         self._check(self.lib.rc_render_rays(self._h, C.byref(r), n, rnd_p, pass_mask, C.byref(cout), stream))
         self._keep = held          # inputs stay alive until the next call (async enqueue)
         return flat, n
+
+    def render_chunks(self, rays: Dict[str, object], chunk: int, n_chunks: int, pass_mask: int, plan, arena, stream_handles):
+        """rc_render_chunks: the chunk loop of render_image in native code.  `rays`: float32 cuda tensors holding
+        n_chunks * chunk rays each (contiguous, the last chunk edge-padded by the caller); `arena`: zero-filled
+        [n_chunks, total] float32 cuda tensor whose rows are laid out by `plan`; chunk i goes to
+        stream_handles[i % len] (raw hipStream_t values).  One ABI call for the whole image."""
+        torch = self._torch
+        r = rc_rays()
+        held = []
+        for k in _RAY_FIELDS:
+            v = rays.get(k)
+            if v is None:
+                continue
+            assert isinstance(v, torch.Tensor) and v.is_cuda and v.dtype is torch.float32 and v.is_contiguous(), k
+            assert v.numel() == n_chunks * chunk * (1 if k in ("near", "far") else 3), (k, tuple(v.shape))
+            held.append(v)
+            setattr(r, k, v.data_ptr())
+        total, _, ids = plan
+        assert arena.is_contiguous() and tuple(arena.shape) == (n_chunks, total)
+        base = arena.data_ptr()
+        cout = rc_outputs()
+        for oid, off in ids:
+            cout.ptr[oid] = base + 4 * off
+        hs = (C.c_void_p * len(stream_handles))(*stream_handles)
+        self._check(self.lib.rc_render_chunks(self._h, C.byref(r), chunk, n_chunks, pass_mask, C.byref(cout), total, hs,
+                                              len(stream_handles)))
+        self._keep = held
 
     def _rays_struct(self, rays):
         r = rc_rays()

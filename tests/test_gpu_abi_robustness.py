@@ -269,3 +269,35 @@ def test_level_kernels_run_time_layout_form_equals_the_compile_time_form(monkeyp
         for k in res[("0", mode)]:
             assert torch.equal(res[("0", mode)][k].cpu(), res[("1", mode)][k].cpu()), (mode, k)
     assert float(res[("0", 1)]["density0"].abs().sum()) > 0.0
+
+
+@pytest.mark.gpu
+def test_render_chunks_equals_one_call_per_chunk():
+    """rc_render_chunks (the chunk loop of render_image inside the library, chunk i on stream i % 2, outputs into row i of
+    one arena) against one rc_render_rays per chunk: bitwise the same rows; passes that need random inputs are refused."""
+    from nrc_amd import rc_ext
+    rc = common.make_rc()
+    chunk, n_chunks = 257, 5
+    rays = nrc_amd.synthetic_rays(chunk * n_chunks, seed=19).hot_fields()
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in rays.items() if k != "lossmult"}
+    keys = ["rgb", "acc", "distance_median", "normals_pred"]
+    plan = rc.output_plan(keys, chunk)
+    total = plan[0]
+    ref = torch.zeros((n_chunks, total), dtype=torch.float32, device="cuda")
+    for i in range(n_chunks):
+        f = {k: v[i * chunk:(i + 1) * chunk].contiguous() for k, v in dev.items()}
+        rc.render_chunk(f, None, rc_ext.RC_PASS_CACHE, plan, ref[i])
+    torch.cuda.synchronize()
+    arena = torch.zeros_like(ref)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ev = torch.cuda.Event(); ev.record()
+    for s_ in streams:
+        s_.wait_event(ev)
+    rc.render_chunks(dev, chunk, n_chunks, rc_ext.RC_PASS_CACHE, plan, arena, [s_.cuda_stream for s_ in streams])
+    for s_ in streams:
+        s_.synchronize()
+    assert torch.equal(arena, ref)
+    assert float(arena.abs().sum()) > 0.0
+    with pytest.raises(rc_ext.RcError):
+        rc.render_chunks(dev, chunk, n_chunks, rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_RESAMPLE, plan, arena,
+                         [s_.cuda_stream for s_ in streams])
