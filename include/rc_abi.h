@@ -374,8 +374,10 @@ int rc_render_transient(rc_handle* h, const rc_rays* rays, const float* cam_orig
  * On-device ray generation: camera_utils.pixels_to_rays + cast_ray_batch
  * (internal/camera_utils.py:896-1072, 1225-1329) for one camera: ProjectionType.PERSPECTIVE / FISHEYE /
  * FISHEYE_EQUISOLID / PANORAMIC, optional radial + tangential distortion (:795-890, Newton undistortion, 10 steps),
- * optional NDC (convert_to_ndc, :50-111; radii then from the offsets between NDC origins, :1058-1066).  No z_range,
- * no pixel jitter.  The outputs are the device arrays rc_rays points to.
+ * optional NDC (convert_to_ndc, :50-111; radii then from the offsets between NDC origins, :1058-1066), optional
+ * sub-pixel jitter offsets (:943-957, handed over as explicit random tensors like rc_randoms) and optional z_range
+ * cropping (cast_ray_batch, :1291-1299; rays_planes_intersection, :1143-1164).  The outputs are the device arrays
+ * rc_cast_outputs points to.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct rc_camera {
   float pixtocam[9];     /* inverse intrinsics, row-major [3,3] (camera_utils.get_pixtocam)              */
@@ -390,6 +392,13 @@ typedef struct rc_camera {
   float distortion[6];      /* k1, k2, k3, k4, p1, p2                                                    */
   int32_t has_ndc;          /* pixtocam_ndc is not None (:1052-1066)                                     */
   float pixtocam_ndc[9];    /* inverse intrinsics of the NDC projection, row-major [3,3]                 */
+  /* -- ABI v4 -- */
+  int32_t has_z_range;      /* z_range is not None: origins += directions * t_min, directions *= t_max - t_min for
+                             * the slab z in [z_range[0], z_range[1]] (camera_utils.py:1291-1299)                 */
+  float z_range[2];
+  const float* pix_dx;      /* [n] device arrays or NULL (jitter = 0): the offsets pixels_to_rays adds to the pixel     */
+  const float* pix_dy;      /* coordinates when jitter > 0 -- U(-0.5, 0.5) or N(0, 0.25), plus a second uniform when
+                             * jitter_scale > 1 (:943-957); the caller draws them (rc_prng_fill + prng.py)         */
 } rc_camera;
 typedef struct rc_cast_outputs {
   float* origins; float* directions; float* viewdirs;   /* [n,3] */

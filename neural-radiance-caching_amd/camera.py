@@ -5,7 +5,8 @@
     render_camera(model, camera, height, width)  trainer.render_primary_rays   engine/trainer.py:812-846 (pose in, image out)
 
 ProjectionType.PERSPECTIVE (the BASELINE scenes), PANORAMIC, FISHEYE, FISHEYE_EQUISOLID; optional radial + tangential
-distortion and NDC rays (camera_utils.py:795-890, 50-111); no z_range, no pixel jitter.
+distortion and NDC rays (camera_utils.py:795-890, 50-111), z_range cropping (:1291-1299) and pixel jitter offsets handed
+over as arrays (:943-957).
 The returned Rays hold torch cuda tensors (nothing crosses PCIe but the 3x3 + 3x4 matrices).
 """
 from __future__ import annotations
@@ -35,6 +36,7 @@ class Camera:
     camtype: str = "perspective"       # ProjectionType value: "perspective", "pano", "fisheye" or "fisheye_equisolid"
     distortion_params: Optional[dict] = None   # {"k1", "k2", "k3", "k4", "p1", "p2"} (camera_utils.py:981-989)
     pixtocam_ndc: Optional[np.ndarray] = None  # [3, 3]: rays in NDC space (camera_utils.py:1052-1066)
+    z_range: Optional[tuple] = None            # (z_min, z_max): rays cropped to that slab (camera_utils.py:1291-1299)
 
 
 def cast_spherical_rays(rc, camtoworld, height: int, width: int, near: float, far: float, light=None) -> Rays:
@@ -45,9 +47,10 @@ def cast_spherical_rays(rc, camtoworld, height: int, width: int, near: float, fa
     return rc.cast_rays(cam, rect=(0, 0, width, height))
 
 
-def cast_ray_batch(rc, camera: Camera, pix_x_int=None, pix_y_int=None, rect=None) -> Rays:
-    """Rays for an explicit pixel batch (int arrays of one shape) or for rect = (x0, y0, width, height)."""
-    return rc.cast_rays(camera, pix_x_int, pix_y_int, rect)
+def cast_ray_batch(rc, camera: Camera, pix_x_int=None, pix_y_int=None, rect=None, pix_jitter=None) -> Rays:
+    """Rays for an explicit pixel batch (int arrays of one shape) or for rect = (x0, y0, width, height).  pix_jitter =
+    (dx, dy): the sub-pixel offsets camera_utils.pixels_to_rays draws for jitter > 0 (explicit random inputs)."""
+    return rc.cast_rays(camera, pix_x_int, pix_y_int, rect, pix_jitter)
 
 
 def render_camera(model, camera: Camera, height: int, width: int, passes=("cache",), rows_per_chunk: Optional[int] = None,

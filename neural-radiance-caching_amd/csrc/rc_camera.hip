@@ -3,9 +3,9 @@
 // Replaces camera_utils.pixels_to_rays (internal/camera_utils.py:896-1072) + cast_ray_batch (:1225-1329), one camera per
 // call: ProjectionType.PERSPECTIVE (the BASELINE scenes), PANORAMIC (= cast_spherical_rays, :1415-1443, the secondary-ray
 // visualisation), FISHEYE / FISHEYE_EQUISOLID (:991-1011), radial + tangential distortion undone by the reference's 10
-// Newton steps (:795-890), NDC rays (convert_to_ndc, :50-111, radii from the NDC origin offsets :1058-1066); no z_range,
-// no pixel jitter.  Same arithmetic in the same order: pixel centre (x + 0.5, y + 0.5, 1) and its
-// +1 neighbours in x and y through pixtocam, flip to OpenGL axes (y, z negated), rotate by camtoworld[:3, :3],
+// Newton steps (:795-890), NDC rays (convert_to_ndc, :50-111, radii from the NDC origin offsets :1058-1066), sub-pixel
+// jitter offsets handed over as tensors (:943-957), z_range cropping (:1143-1164, 1291-1299).  Same arithmetic in the
+// same order: pixel centre (x + 0.5, y + 0.5, 1) and its +1 neighbours in x and y through pixtocam, flip to OpenGL axes (y, z negated), rotate by camtoworld[:3, :3],
 // viewdirs = directions / |directions|, radii = 0.5 (|dx - d| + |dy - d|) * 2 / sqrt(12).
 #include "rc_internal.h"
 
@@ -30,7 +30,10 @@ __global__ void k_cast_rays(RcCastArgs a) {
   float d[3][3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const float x = (float)(px + (k == 1 ? 1 : 0)) + 0.5f, y = (float)(py + (k == 2 ? 1 : 0)) + 0.5f;
+    // pix_to_dir(pix_x_int (+ 1) + dx, pix_y_int (+ 1) + dy): the integer sum, then the offset, then the half pixel
+    float x = (float)(px + (k == 1 ? 1 : 0)), y = (float)(py + (k == 2 ? 1 : 0));
+    if (a.pix_dx) { x = x + a.pix_dx[i]; y = y + a.pix_dy[i]; }
+    x = x + 0.5f; y = y + 0.5f;
     float cx, cy, cz;
     mat3_vec(a.pixtocam, x, y, 1.0f, cx, cy, cz);
     if (a.has_distortion) {
@@ -103,6 +106,18 @@ __global__ void k_cast_rays(RcCastArgs a) {
     return sqrtf((ex * ex + ey * ey) + ez * ez);
   };
   const float radius = (0.5f * (dist(1) + dist(2))) * 2.0f / 3.4641016151377544f;       // sqrt(12)
+  if (a.has_z_range) {
+    // rays_planes_intersection (:1143-1164) + the crop of cast_ray_batch (:1291-1299); np.minimum / np.maximum
+    // propagate a NaN (directions.z == 0 with the origin on a plane), fminf / fmaxf would drop it
+    const float t1 = (a.z_lo - o[0][2]) / d[0][2], t2 = (a.z_hi - o[0][2]) / d[0][2];
+    const bool nan = (t1 != t1) || (t2 != t2);
+    const float t_min = nan ? __builtin_nanf("") : fminf(t1, t2), t_max = nan ? __builtin_nanf("") : fmaxf(t1, t2);
+    if (!(t_max < t_min)) {
+      const float span = t_max - t_min;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { o[0][c] = o[0][c] + d[0][c] * t_min; d[0][c] = d[0][c] * span; }
+    }
+  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     if (a.origins) a.origins[3 * i + c] = o[0][c];

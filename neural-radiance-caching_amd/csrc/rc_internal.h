@@ -350,6 +350,8 @@ struct RcCastArgs {
   int32_t camtype;                                  // 0 perspective, 1 panoramic, 2 fisheye, 3 fisheye (equisolid)
   int32_t has_distortion; float dist[6];            // k1 k2 k3 k4 p1 p2
   int32_t has_ndc; float ndc_xmult, ndc_ymult;      // 1 / pixtocam_ndc[0][2], 1 / pixtocam_ndc[1][2]
+  int32_t has_z_range; float z_lo, z_hi;            // cast_ray_batch's z_range
+  const float* pix_dx; const float* pix_dy;         // sub-pixel jitter offsets [n] or NULL
   float* origins; float* directions; float* viewdirs; float* radii; float* imageplane; float* look; float* up;
   float* lights; float* near; float* far;
 };

@@ -404,7 +404,7 @@ def _strip_device_axis(a, ndim: int):
 def _cast_pixels(model: Model, cameras, lights, pixels: Pixels, camtype) -> Rays:
     """camera_utils.cast_ray_batch(cameras, lights, pixels, camtype) (internal/camera_utils.py:1225-1329) on the device
     (rc_cast_rays): per-pixel camera lookup by `cam_idx`, rays with the batch shape of the pixels.  cameras =
-    (pixtocams, camtoworlds, distortion_params, pixtocam_ndc[, z_range]) as the reference's tuple; z_range must be None."""
+    (pixtocams, camtoworlds, distortion_params, pixtocam_ndc[, z_range]) as the reference's tuple."""
     import torch
 
     from .camera import Camera
@@ -412,8 +412,7 @@ def _cast_pixels(model: Model, cameras, lights, pixels: Pixels, camtype) -> Rays
         raise AssertionError("When passing Pixels into render_eval_fn, cameras and camtype needs to be not None. "
                              f"Got cameras={cameras} camtype={camtype}.")      # train_utils.py:3785-3789
     cams = tuple(cameras)
-    if len(cams) > 4 and cams[4] is not None:
-        raise NotImplementedError("z_range is not supported by rc_cast_rays")
+    z_range = None if len(cams) <= 4 or cams[4] is None else tuple(float(v) for v in np.asarray(_strip_device_axis(cams[4], 1)).reshape(-1)[:2])
     distortion = cams[2] if len(cams) > 2 else None
     ndc = None if len(cams) <= 3 or cams[3] is None else _strip_device_axis(cams[3], 2)
     ctype = getattr(camtype, "value", camtype)
@@ -433,7 +432,7 @@ def _cast_pixels(model: Model, cameras, lights, pixels: Pixels, camtype) -> Rays
         c2w = camtoworlds if camtoworlds.ndim == 2 else camtoworlds[i]
         light = None if lights is None else (lights if lights.ndim == 1 else lights[i])     # lights[cam_idx], :1288
         return Camera(pixtocam=p2c, camtoworld=c2w[:3, :4], light=light, near=0.0, far=0.0, camtype=ctype,
-                      distortion_params=distortion, pixtocam_ndc=ndc)
+                      distortion_params=distortion, pixtocam_ndc=ndc, z_range=z_range)
 
     uniq = np.unique(cam_idx)
     if len(uniq) == 1:

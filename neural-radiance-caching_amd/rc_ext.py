@@ -134,7 +134,8 @@ class rc_camera(C.Structure):
     _fields_ = [("pixtocam", C.c_float * 9), ("camtoworld", C.c_float * 12), ("light", C.c_float * 3),
                 ("near", C.c_float), ("far", C.c_float), ("camtype", C.c_int32),
                 ("has_distortion", C.c_int32), ("distortion", C.c_float * 6),
-                ("has_ndc", C.c_int32), ("pixtocam_ndc", C.c_float * 9)]
+                ("has_ndc", C.c_int32), ("pixtocam_ndc", C.c_float * 9),
+                ("has_z_range", C.c_int32), ("z_range", C.c_float * 2), ("pix_dx", C.c_void_p), ("pix_dy", C.c_void_p)]
 
 
 CAST_OUTPUTS = (("origins", 3), ("directions", 3), ("viewdirs", 3), ("radii", 1), ("imageplane", 2), ("look", 3), ("up", 3),
@@ -634,11 +635,12 @@ class RadianceCache:
         self._check(self.lib.rc_prng_fill(self._h, k, modes[mode], float(minval), float(maxval), n, out.data_ptr(), stream))
         return out
 
-    def cast_rays(self, camera, pix_x_int=None, pix_y_int=None, rect=None):
+    def cast_rays(self, camera, pix_x_int=None, pix_y_int=None, rect=None, pix_jitter=None):
         """rc_cast_rays: rays of `camera` (pixtocam [3,3], camtoworld [3,4], light, near, far; optional camtype,
-        distortion_params, pixtocam_ndc as in camera_utils.pixels_to_rays) for an explicit
+        distortion_params, pixtocam_ndc, z_range as in camera_utils.pixels_to_rays / cast_ray_batch) for an explicit
         pixel batch (two int arrays of one shape) or for rect = (x0, y0, width, height), as a Rays of cuda tensors
-        with the batch shape of the pixels ([h, w, .] for a rectangle)."""
+        with the batch shape of the pixels ([h, w, .] for a rectangle).  pix_jitter = (dx, dy): the sub-pixel offsets
+        the reference draws when jitter > 0 (camera_utils.py:943-957), float32 arrays of the pixels' shape."""
         from .rays import Rays
         torch = self._torch
         cam = rc_camera()
@@ -663,6 +665,10 @@ class RadianceCache:
             cam.has_ndc = 1
             for i, v in enumerate(np.asarray(ndc, np.float32).reshape(9)):
                 cam.pixtocam_ndc[i] = float(v)
+        zr = getattr(camera, "z_range", None)
+        if zr is not None:
+            cam.has_z_range = 1
+            cam.z_range[0], cam.z_range[1] = float(zr[0]), float(zr[1])
         dev = f"cuda:{self.device}"
         if rect is not None:
             x0, y0, w, hgt = (int(v) for v in rect)
@@ -673,6 +679,12 @@ class RadianceCache:
             if px.shape != py.shape:
                 raise ValueError("pix_x_int and pix_y_int must have the same shape")
             shape, n, x0, y0, w, hgt = tuple(px.shape), px.numel(), 0, 0, 0, 0
+        jit = None
+        if pix_jitter is not None:
+            jit = [self._dev(np.ascontiguousarray(j, dtype=np.float32) if not isinstance(j, torch.Tensor) else j).reshape(-1) for j in pix_jitter]
+            if jit[0].numel() != n or jit[1].numel() != n:
+                raise ValueError("pix_jitter: two arrays with one value per pixel")
+            cam.pix_dx, cam.pix_dy = jit[0].data_ptr(), jit[1].data_ptr()
         out = rc_cast_outputs()
         t = {}
         for k, width in CAST_OUTPUTS:
@@ -681,7 +693,7 @@ class RadianceCache:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         self._check(self.lib.rc_cast_rays(self._h, C.byref(cam), px.data_ptr() if px is not None else None,
                                           py.data_ptr() if py is not None else None, n, x0, y0, w, hgt, C.byref(out), stream))
-        self._keep = [px, py]
+        self._keep = [px, py, jit]
         ones = torch.ones(shape + (1,), dtype=torch.float32, device=dev)
         zi = torch.zeros(shape + (1,), dtype=torch.int32, device=dev)
         return Rays(origins=t["origins"], lights=t["lights"], directions=t["directions"], viewdirs=t["viewdirs"],

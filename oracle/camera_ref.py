@@ -2,7 +2,8 @@
 
 Restates camera_utils.pixels_to_rays (internal/camera_utils.py:896-1072) and cast_ray_batch (:1225-1329):
 ProjectionType.PERSPECTIVE (the BASELINE scenes), PANORAMIC, FISHEYE, FISHEYE_EQUISOLID, distortion_params
-(_radial_and_tangential_undistort, :795-890), pixtocam_ndc (convert_to_ndc, :50-111); z_range=None, jitter=0,
+(_radial_and_tangential_undistort, :795-890), pixtocam_ndc (convert_to_ndc, :50-111), z_range (rays_planes_intersection,
+:1143-1164, 1291-1299), jitter with the offsets (dx, dy) handed over instead of drawn from a key (:943-957);
 xnp=numpy (the dataset / eval path casts with numpy).
 """
 from __future__ import annotations
@@ -64,7 +65,7 @@ def convert_to_ndc(origins, directions, pixtocam, near=1.0):
 
 
 def pixels_to_rays(pix_x_int, pix_y_int, pixtocam, camtoworld, dtype=np.float32, camtype="perspective",
-                   distortion_params=None, pixtocam_ndc=None):
+                   distortion_params=None, pixtocam_ndc=None, pix_jitter=None):
     pix_x_int = np.asarray(pix_x_int)
     pix_y_int = np.asarray(pix_y_int)
     pixtocam = np.asarray(pixtocam, dtype)
@@ -73,9 +74,12 @@ def pixels_to_rays(pix_x_int, pix_y_int, pixtocam, camtoworld, dtype=np.float32,
     def pix_to_dir(x, y):
         return np.stack([x + 0.5, y + 0.5, np.ones_like(x)], axis=-1)
 
-    px = pix_x_int.astype(dtype)
-    py = pix_y_int.astype(dtype)
-    stacked = np.stack([pix_to_dir(px, py), pix_to_dir(px + 1, py), pix_to_dir(px, py + 1)], axis=0)
+    # (:943-966) dx = dy = 0.0 without jitter; with it the reference adds the offsets to the INTEGER coordinates (+ 1 for
+    # the neighbours first), the sum is float32
+    dxj, dyj = (dtype(0.0), dtype(0.0)) if pix_jitter is None else (np.asarray(pix_jitter[0], dtype), np.asarray(pix_jitter[1], dtype))
+    px0, px1 = pix_x_int.astype(dtype) + dxj, (pix_x_int + 1).astype(dtype) + dxj
+    py0, py1 = pix_y_int.astype(dtype) + dyj, (pix_y_int + 1).astype(dtype) + dyj
+    stacked = np.stack([pix_to_dir(px0, py0), pix_to_dir(px1, py0), pix_to_dir(px0, py1)], axis=0)
     mat_vec_mul = lambda A, b: np.matmul(A, b[..., None])[..., 0]
     cam_dirs = mat_vec_mul(pixtocam, stacked)
     if distortion_params is not None:
@@ -113,11 +117,26 @@ def pixels_to_rays(pix_x_int, pix_y_int, pixtocam, camtoworld, dtype=np.float32,
                 look=look, up=up)
 
 
+def rays_planes_intersection(z_min, z_max, origins, directions):
+    """camera_utils.rays_planes_intersection (:1143-1164)."""
+    t1 = (z_min - origins[..., 2]) / directions[..., 2]
+    t2 = (z_max - origins[..., 2]) / directions[..., 2]
+    return np.minimum(t1, t2), np.maximum(t1, t2)
+
+
 def cast_ray_batch(pixtocam, camtoworld, light, pix_x_int, pix_y_int, near, far, dtype=np.float32, camtype="perspective",
-                   distortion_params=None, pixtocam_ndc=None):
+                   distortion_params=None, pixtocam_ndc=None, z_range=None, pix_jitter=None):
     """cast_ray_batch for one camera: rays + lights = lights[cam_idx], cam_origins = origins, near / far from Pixels."""
-    r = pixels_to_rays(pix_x_int, pix_y_int, pixtocam, camtoworld, dtype, camtype, distortion_params, pixtocam_ndc)
+    r = pixels_to_rays(pix_x_int, pix_y_int, pixtocam, camtoworld, dtype, camtype, distortion_params, pixtocam_ndc, pix_jitter)
     shape = r["directions"].shape
+    if z_range is not None:                                  # :1291-1299
+        origins, directions = r["origins"], r["directions"]
+        t_min, t_max = rays_planes_intersection(dtype(z_range[0]), dtype(z_range[1]), origins, directions)
+        t_min = np.broadcast_to(t_min[..., None], origins.shape)
+        t_max = np.broadcast_to(t_max[..., None], origins.shape)
+        hit_mask = t_max < t_min
+        r["origins"] = np.where(hit_mask, origins, origins + directions * t_min)
+        r["directions"] = np.where(hit_mask, directions, directions * (t_max - t_min))
     r["lights"] = np.broadcast_to(np.asarray(light, dtype), shape)
     r["cam_origins"] = r["origins"]
     r["near"] = np.full(shape[:-1] + (1,), near, dtype)

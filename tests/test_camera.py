@@ -206,3 +206,60 @@ def test_cast_rays_distortion_fisheye_ndc_on_device(case):
         # 2e-6 like the pinhole test; the radii of the NDC rays are differences of two NDC origins ~1 apart (cancellation)
         tol = 2e-5 if ("ndc" in case and k == "radii") else 4e-6
         assert np.abs(g - ref[k]).max() <= tol * max(1.0, np.abs(ref[k]).max()), (k, np.abs(g - ref[k]).max())
+
+
+def test_z_range_and_pixel_jitter_known_answers():
+    """cast_ray_batch(z_range=...) crops a ray to the slab between two z planes (camera_utils.py:1143-1164, 1291-1299):
+    the new origin lies on the nearer plane, origin + direction on the farther one; viewdirs and radii are untouched.
+    Pixel jitter offsets (:943-957) move a ray exactly like a fractional pixel coordinate would."""
+    H, W, f = 6, 8, 9.0
+    p2c = camera_ref.get_pixtocam(f, W, H)
+    c2w = _lookat([0.5, -2.0, 5.0])
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H), indexing="xy")
+    plain = camera_ref.cast_ray_batch(p2c, c2w, [0, 0, 5.0], xs, ys, 2.0, 6.0, np.float64)
+    crop = camera_ref.cast_ray_batch(p2c, c2w, [0, 0, 5.0], xs, ys, 2.0, 6.0, np.float64, z_range=(-1.0, 1.5))
+    # every ray of this camera points downwards: it enters at z = 1.5 and leaves at z = -1
+    assert (plain["directions"][..., 2] < 0).all()
+    assert np.allclose(crop["origins"][..., 2], 1.5) and np.allclose((crop["origins"] + crop["directions"])[..., 2], -1.0)
+    # the cropped ray is the same line: origin' - origin and direction' are parallel to direction
+    for v in (crop["origins"] - plain["origins"], crop["directions"]):
+        assert np.allclose(np.cross(v, plain["directions"]), 0.0, atol=1e-12)
+    assert np.array_equal(crop["viewdirs"], plain["viewdirs"]) and np.array_equal(crop["radii"], plain["radii"])
+    assert crop["cam_origins"] is crop["origins"]
+    # jitter: (dx, dy) = (0.25, -0.5) on integer pixel (3, 2) = the direction through pixel coordinates (3.75, 2.0)
+    dx, dy = np.full(xs.shape, 0.25), np.full(xs.shape, -0.5)
+    jit = camera_ref.pixels_to_rays(xs, ys, p2c, c2w, np.float64, pix_jitter=(dx, dy))
+    cam_dir = p2c @ np.array([3 + 0.25 + 0.5, 2 - 0.5 + 0.5, 1.0])
+    want = c2w[:, :3] @ (cam_dir * np.array([1.0, -1.0, -1.0]))
+    assert np.allclose(jit["directions"][2, 3], want, atol=1e-12)
+    assert np.allclose(jit["radii"], plain["radii"])              # a pinhole's pixel footprint does not depend on the offset
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["z_range", "jitter", "jitter+z_range+distortion"])
+def test_cast_rays_z_range_and_jitter_on_device(case):
+    from nrc_amd import rc_ext
+    rc = rc_ext.RadianceCache(nrc_amd.hotdog_config(), 0)
+    H, W, f = 26, 38, 33.0
+    p2c = nrc_amd.get_pixtocam(f, W, H)
+    c2w = _lookat([1.0, -2.5, 4.0])
+    kw = {}
+    if "z_range" in case:
+        kw["z_range"] = (-0.75, 1.25)
+    if "distortion" in case:
+        kw["distortion_params"] = DIST
+    cam = nrc_amd.Camera(p2c, c2w, light=[1.0, -2.4, 4.1], near=0.0, far=1.0, **kw)
+    rng = np.random.default_rng(12)
+    ys, xs = rng.integers(0, H, size=(5, 61)), rng.integers(0, W, size=(5, 61))
+    jit = (rng.uniform(-0.5, 0.5, xs.shape).astype(np.float32), (rng.normal(size=xs.shape) * 0.5).astype(np.float32)) if "jitter" in case else None
+    ref = camera_ref.cast_ray_batch(cam.pixtocam, cam.camtoworld, cam.light, xs, ys, 0.0, 1.0, distortion_params=kw.get("distortion_params"),
+                                    z_range=kw.get("z_range"), pix_jitter=jit)
+    got = nrc_amd.cast_ray_batch(rc, cam, xs, ys, pix_jitter=jit)
+    torch.cuda.synchronize()
+    for k in ("origins", "directions", "viewdirs", "radii", "imageplane", "look", "up", "lights", "near", "far"):
+        g = getattr(got, k).cpu().numpy()
+        assert g.shape == ref[k].shape, k
+        assert np.abs(g - ref[k]).max() <= 4e-6 * max(1.0, np.abs(ref[k]).max()), (k, np.abs(g - ref[k]).max())
+    if jit is None:
+        with pytest.raises(ValueError):
+            rc.cast_rays(cam, xs, ys, pix_jitter=(np.zeros(3, np.float32), np.zeros(3, np.float32)))

@@ -117,8 +117,8 @@ def test_pixels_branch_casts_on_the_device():
         assert torch.equal(out["rgb"][0, 0][torch.from_numpy(sel).cuda()], ref["rgb"])
     with pytest.raises(AssertionError):
         M.create_render_fn(m, None)(None, None, 1.0, cameras, lights, pixels, ("cache",), None)      # camtype unknown
-    # the reference's cameras tuple also carries distortion_params and pixtocam_ndc (camera_utils.py:1295-1306): both go
-    # through to rc_cast_rays; z_range does not exist there
+    # the reference's cameras tuple also carries distortion_params, pixtocam_ndc and z_range (camera_utils.py:1262-1299):
+    # all of them go through to rc_cast_rays
     dist = dict(k1=0.05, k2=-0.01, p1=0.001, p2=0.0)
     out_d, _ = pfn(None, None, 1.0, (p2c[None], c2w[None], dist, None, None), lights, pixels, ("cache",), None)
     sel = np.nonzero(cam_idx == 0)[0]
@@ -126,8 +126,13 @@ def test_pixels_branch_casts_on_the_device():
     ref = m.apply(None, None, nrc_amd.cast_ray_batch(m.rc, cam, px[sel].astype(np.int32), py[sel].astype(np.int32)))["render"]
     assert torch.equal(out_d["rgb"][0, 0][torch.from_numpy(sel).cuda()], ref["rgb"])
     assert not torch.equal(out_d["rgb"], out["rgb"])
-    with pytest.raises(NotImplementedError):
-        pfn(None, None, 1.0, (p2c[None], c2w[None], None, None, np.array([0.1, 1.0])), lights, pixels, ("cache",), None)
+    zr = np.array([0.1, 1.0], np.float32)
+    out_z, _ = pfn(None, None, 1.0, (p2c[None], c2w[None], None, None, zr[None]), lights, pixels, ("cache",), None)
+    cam = nrc_amd.Camera(pixtocam=p2c[0], camtoworld=c2w[0], light=c2w[0][:, 3], near=2.0, far=6.0, z_range=(0.1, 1.0))
+    rays_z = nrc_amd.cast_ray_batch(m.rc, cam, px[sel].astype(np.int32), py[sel].astype(np.int32))
+    ref = m.apply(None, None, rays_z)["render"]
+    assert torch.equal(out_z["rgb"][0, 0][torch.from_numpy(sel).cuda()], ref["rgb"])
+    assert float((rays_z.origins[..., 2] - 1.0).abs().max()) <= 1e-6          # the camera looks down -z from z ~ 4: cropped to the upper plane
 
 
 def test_updated_variables_are_reloaded():
