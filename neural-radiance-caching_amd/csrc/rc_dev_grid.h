@@ -61,17 +61,16 @@ __device__ __forceinline__ void contract3(float& x, float& y, float& z, float ra
 
 // Trilinear lookup of level L at the (already contracted) position (x, y, z), in two halves so that a
 // caller can put the fetches of several levels in flight before combining any of them:
-//   grid_fetch   : cell + weights, issues the 8 corner loads (straight-line code: dense and hashed
-//                  addressing are both computed and selected, a zero-padded corner loads entry 0 and is
-//                  masked afterwards)
+//   grid_fetch   : cell + weights, the eight entry indices (one branch on the level's kind; a zero-padded
+//                  corner reads entry 0 and is masked afterwards), then the 8 corner loads
 //   grid_combine : acc[F] interpolated features (NOT yet scaled by the precondition factor);
 //                  jacc[3*F] (JAC): d feature / d loc_a for the three location axes in the level's own
 //                  axis order.  Corners are combined in the reference's order (b2 fastest).
 template <int F> struct Corners { Vec<F> val[8]; float cw[3]; uint32_t zero_mask; };
 
 // (x01, y01, z01) = unit_box(bbox, contracted position): level independent, computed once per point.
-// `dense`, `size`, `mask`, `entries` must be wave-uniform (one branch per level, both sides straight-line);
-// `table` may differ per lane.  The per-axis terms of the index are computed once per level (two
+// `size`, `mask`, `entries` and `table` may differ per lane (a wave that holds two levels on its two half-waves), and so
+// may `dense` (see grid_fetch).  The per-axis terms of the index are computed once per level (two
 // candidates per axis), a corner then costs an xor/add, the address and the load.
 // x01 = (x - bbox_min) / (bbox_max - bbox_min) (grid_utils.py:820, 863)
 __device__ __forceinline__ float unit_box(float bbox, float x) { return rc_div(x - (-bbox), bbox - (-bbox)); }

@@ -216,6 +216,27 @@ def cache_pass_randoms(model_rng, n_rays: int, num_samples: Sequence[int], resam
     return rnd
 
 
+def pixel_jitter(rng, shape, jitter: int = 1, jitter_scale: float = 1.0):
+    """The sub-pixel offsets camera_utils.pixels_to_rays draws when jitter > 0 (internal/camera_utils.py:943-957):
+    key, rng = split(rng); k1, k2 = split(key); jitter == 1: U(0, 1) - 0.5 each, otherwise N(0, 1) * 0.5; with
+    jitter_scale > 1 a second uniform pair from split(k1) is added.  Returns (dx, dy) float32 arrays of `shape` --
+    what rc_camera.pix_dx / pix_dy (cast_ray_batch(..., pix_jitter=...)) take.  As with the other key paths of this
+    module the call ORDER is restated from the source and cannot be checked against a JAX run here."""
+    key, _ = split(as_key(rng))
+    k1, k2 = split(key)
+    if jitter == 1:
+        dx = uniform(k1, shape) - np.float32(0.5)
+        dy = uniform(k2, shape) - np.float32(0.5)
+    else:
+        dx = normal(k1, shape) * np.float32(0.5)
+        dy = normal(k2, shape) * np.float32(0.5)
+    if jitter_scale > 1.0:
+        k1, k2 = split(k1)
+        dx = dx + (uniform(k1, shape) - np.float32(0.5))
+        dy = dy + (uniform(k2, shape) - np.float32(0.5))
+    return dx.astype(np.float32), dy.astype(np.float32)
+
+
 def light_vmf_noise(shape, seed: int = 1) -> np.ndarray:
     """Constant mean noise of LightMLP.get_vmfs (light_sampler.py:135-144): normal(random_split(PRNGKey(seed))[0],
     vmf_params.shape[:-1] + (3,)); the caller scales it by vmf_scale / 2."""

@@ -249,3 +249,21 @@ def test_material_stage_from_a_key_matches_the_oracle_on_the_same_tensors():
     for k in ("rgb", "diffuse_rgb", "specular_rgb", "lighting_irradiance", "material_albedo"):
         d = np.abs(out[k].cpu().numpy() - r[k].numpy().reshape(out[k].shape))[ok]
         assert d.max() <= 1e-4, (k, d.max())
+
+
+def test_pixel_jitter_offsets():
+    """prng.pixel_jitter: the offsets of camera_utils.pixels_to_rays (jitter > 0).  Range / moments per mode, the
+    second uniform pair with jitter_scale > 1, determinism, independence of dx and dy."""
+    from nrc_amd import prng
+    key = prng.PRNGKey(5)
+    dx, dy = prng.pixel_jitter(key, (64, 96), jitter=1)
+    assert dx.dtype == np.float32 and dx.shape == (64, 96)
+    assert dx.min() >= -0.5 and dx.max() < 0.5 and abs(float(dx.mean())) < 0.02 and abs(float(dx.std()) - 12 ** -0.5) < 0.01
+    assert abs(float(np.corrcoef(dx.ravel(), dy.ravel())[0, 1])) < 0.05
+    a, b = prng.pixel_jitter(key, (64, 96), jitter=1)
+    assert np.array_equal(a, dx) and np.array_equal(b, dy)
+    gx, gy = prng.pixel_jitter(key, (64, 96), jitter=2)
+    assert abs(float(gx.std()) - 0.5) < 0.02 and abs(float(gy.mean())) < 0.03 and np.abs(gx).max() > 1.0
+    sx, _ = prng.pixel_jitter(key, (64, 96), jitter=1, jitter_scale=2.0)
+    extra = sx - dx
+    assert extra.min() >= -0.5 - 1e-6 and extra.max() <= 0.5 + 1e-6 and float(extra.std()) > 0.2      # a second U(-0.5, 0.5)
