@@ -645,6 +645,7 @@ int ensure_workspace(rc_handle* h, int64_t n) {
   if ((rc = ws_alloc(h, "inds", n))) return rc;
   if ((rc = ws_alloc(h, "src_idx", n))) return rc;
   if ((rc = ws_alloc(h, "filt_weight", n))) return rc;
+  if ((rc = ws_alloc(h, "acc_sel", n))) return rc;
   // lean resampling pass: last-level features / hidden vector / predicted normals of the picked samples only
   if ((rc = ws_alloc(h, "feat_sel", 32 * n))) return rc;
   if ((rc = ws_alloc(h, "hbuf_sel", ((n + 31) / 32) * 32 * 64))) return rc;
@@ -1173,6 +1174,7 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     ra.n_rays = n; ra.S = S2; ra.tdist = W(h, "tdist" + LL); ra.density = W(h, "density" + LL);
     ra.directions = rays->directions; ra.gumbel = rnd->gumbel; ra.inds_in = rnd->resample_inds;
     ra.inds_out = (int32_t*)W(h, "inds"); ra.filt_weight = W(h, "filt_weight"); ra.weights = W(h, "weights" + LL);
+    ra.acc_out = W(h, "acc_sel");
     ra.src_out = (int32_t*)W(h, "src_idx");
     rc_launch_resample(ra, st);
     src = (const int32_t*)W(h, "src_idx");
@@ -1240,7 +1242,13 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
       ca.out.ptr[RC_OUT_RGB] = W(h, "rgb_noenv");
       ca.out.ptr[RC_OUT_ACC] = W(h, "acc_ws");
     }
-    rc_launch_composite(ca, st);
+    // one resampled sample per ray and nothing but rgb / acc wanted (the batched secondary trace): the weights and their
+    // sum are k_resample's, one thread per ray finishes (17 -> 3 us for 32 768 rays; same bits)
+    bool pick_only = resample;
+    for (int id = 0; id < RC_OUT_COUNT && pick_only; ++id)
+      if (ca.out.ptr[id] && id != RC_OUT_RGB && id != RC_OUT_ACC) pick_only = false;
+    if (pick_only) rc_launch_composite_pick(n, W(h, "shade"), W(h, "filt_weight"), W(h, "acc_sel"), ca.bg, ca.out.ptr[RC_OUT_RGB], ca.out.ptr[RC_OUT_ACC], st);
+    else rc_launch_composite(ca, st);
   }
   if (secondary) {
     const bool use_env = !(A.mask & RC_PASS_NO_ENVMAP);

@@ -121,6 +121,7 @@ struct RcResampleArgs {
   int32_t* inds_out;          // [n]
   float* filt_weight;         // [n]
   float* weights;             // [n*S] out (weights_no_filter)
+  float* acc_out;             // [n] or nullptr: sum of the weights, added as k_composite adds it (rc_launch_composite_pick)
   int32_t* src_out;           // [n] or nullptr: flat index ray * S + pick of the picked sample (per-pick lookups read through it)
   // material stage: position and predicted normal of the picked sample, gathered here (all four or none)
   const float* means;         // SoA [3][n*S]
@@ -129,6 +130,11 @@ struct RcResampleArgs {
   float* nrm_out;             // [n,3]
 };
 void rc_launch_resample(const RcResampleArgs& a, hipStream_t stream);
+// k_composite for the case "one resampled sample per ray, only rgb and acc wanted" (the batched secondary trace): the
+// weights and their sum are k_resample's, the only non-zero filtered weight sits on the pick -- one thread per ray.
+// shade_rgb: the three colour channels of the shader's output, [3][n].  Same values, bit for bit.
+void rc_launch_composite_pick(int64_t n, const float* shade_rgb, const float* filt_weight, const float* acc, float bg,
+                              float* out_rgb, float* out_acc, hipStream_t stream);
 // out[0] = power_ladder(near'), out[1] = power_ladder(far') with near' / far' as sample_level_ray derives them from
 // (near, far) for a secondary ray without a surface normal
 void rc_launch_ladder_bounds(float near, float far, float far_clamp, float p, float premult, float* out, hipStream_t stream);

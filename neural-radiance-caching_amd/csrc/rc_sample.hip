@@ -63,6 +63,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_resample(RcResampleArgs
   const float dens = act ? a.density[ray * S + lane] : 0.0f;
   const float w = alpha_weight(dens, t0, t1, dnorm, act, lane);
   if (act) a.weights[ray * S + lane] = w;
+  if (a.acc_out) {                                 // render.py:202, as k_composite adds it
+    const float acc = wave_sum(w);
+    if (lane == 0) a.acc_out[ray] = acc;
+  }
   // logits = safe_log(w + 0) * 1 ; probs = softmax (models.py:207-209)
   const float logit = safe_log(w);
   const float m = wave_max(act ? logit : -INFINITY);
@@ -257,6 +261,23 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
 
 }  // namespace
 
+// see rc_internal.h.  k_composite in this case: rgb[c] = sum over the lanes of w * shade with w = filt_weight on the
+// picked lane and 0 elsewhere (adding +0 is exact, the product is never -0: both factors are >= 0), + max(0, 1 - acc) * bg.
+__global__ void k_composite_pick(int64_t n, const float* __restrict__ shade_rgb, const float* __restrict__ filt_weight,
+                                 const float* __restrict__ acc_in, float bg, float* __restrict__ out_rgb,
+                                 float* __restrict__ out_acc) {
+  const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= n) return;
+  const float acc = acc_in[ray];
+  if (out_rgb) {
+    const float w = filt_weight[ray];
+    const float bgw = fmaxf(0.0f, 1.0f - acc) * bg;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out_rgb[3 * ray + c] = w * shade_rgb[(int64_t)c * n + ray] + bgw;
+  }
+  if (out_acc) out_acc[ray] = acc;
+}
+
 __global__ void k_ladder_bounds(float near, float far, float far_clamp, float p, float premult, float* out) {
   far = fminf(far, far_clamp);                                      // models.py:670-673 (sample_level_ray, secondary)
   out[0] = power_ladder(near, p, premult);
@@ -293,4 +314,11 @@ void rc_launch_composite(const RcCompositeArgs& a, hipStream_t stream) {
   if (a.n_rays <= 0) return;
   dim3 grid((unsigned)((a.n_rays + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);
   hipLaunchKernelGGL(k_composite, grid, block, 0, stream, a);
+}
+
+void rc_launch_composite_pick(int64_t n, const float* shade_rgb, const float* filt_weight, const float* acc, float bg,
+                              float* out_rgb, float* out_acc, hipStream_t stream) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_composite_pick, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, shade_rgb, filt_weight, acc, bg,
+                     out_rgb, out_acc);
 }

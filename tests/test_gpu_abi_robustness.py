@@ -301,3 +301,23 @@ def test_render_chunks_equals_one_call_per_chunk():
     with pytest.raises(rc_ext.RcError):
         rc.render_chunks(dev, chunk, n_chunks, rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_RESAMPLE, plan, arena,
                          [s_.cuda_stream for s_ in streams])
+
+
+@pytest.mark.gpu
+def test_pick_composite_equals_the_general_composite():
+    """With one resampled sample per ray and only rgb / acc requested the compositing is finished by one thread per ray
+    from k_resample's weight sum (rc_launch_composite_pick); any further output selects the wave-per-ray k_composite.
+    rgb and acc are the same bits either way: primary rays with forced resampling, and secondary rays."""
+    from nrc_amd import rc_ext
+    rc = common.make_rc()
+    n = 3001
+    rays = nrc_amd.synthetic_rays(n, seed=23).hot_fields()
+    rnd = {"jitter": common.jitters(n, seed=4), "gumbel": np.random.default_rng(8).gumbel(size=(n, 32)).astype(np.float32)}
+    srays, srnd = common.secondary_case(n, seed=29)
+    for fields, r, mask, extra in ((rays, rnd, rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_RESAMPLE, "means"),
+                                   (srays, srnd, rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_SECONDARY | rc_ext.RC_PASS_NO_ENVMAP, "distance_mean")):
+        a = {k: v.clone() for k, v in rc.render_rays(fields, r, mask, outputs=["rgb", "acc"]).items()}
+        b = {k: v.clone() for k, v in rc.render_rays(fields, r, mask, outputs=["rgb", "acc", extra]).items()}
+        torch.cuda.synchronize()
+        assert torch.equal(a["rgb"], b["rgb"]) and torch.equal(a["acc"], b["acc"]), mask
+        assert float(a["rgb"].abs().sum()) > 0.0 and float(a["acc"].sum()) > 0.0
