@@ -81,7 +81,9 @@ __device__ __forceinline__ float ggx_d(float c, float a) {
 // ---------------------------------------------------------------------------------------------
 // One workgroup takes MH_PTS points: thread t keeps column t of the first layer in registers, so the 16 KB of w0 is
 // read once per MH_PTS points instead of once per point.  Sums run in the same order as the one-point form.
-constexpr int MH_PTS = 16;
+// MH_PTS: 16 for large batches; 4 for the 1024 shading points of a material step (256 workgroups instead of 64: that
+// call sits on the step's critical path and is latency, not traffic).
+template <int MH_PTS>
 __global__ __launch_bounds__(128) void k_material_head(RcMatHeadArgs a) {
   __shared__ float s_feat[MH_PTS][32], s_h[MH_PTS][128], s_out[MH_PTS][10];
   const int64_t p0 = (int64_t)blockIdx.x * MH_PTS;
@@ -487,7 +489,8 @@ __global__ __launch_bounds__(256) void k_material_integrate(RcMatIntegrateArgs a
 
 void rc_launch_material_head(const RcMatHeadArgs& a, hipStream_t st) {
   if (a.n <= 0) return;
-  hipLaunchKernelGGL(k_material_head, dim3((unsigned)((a.n + MH_PTS - 1) / MH_PTS)), dim3(128), 0, st, a);
+  if (a.n <= 8192) hipLaunchKernelGGL(k_material_head<4>, dim3((unsigned)((a.n + 3) / 4)), dim3(128), 0, st, a);
+  else hipLaunchKernelGGL(k_material_head<16>, dim3((unsigned)((a.n + 15) / 16)), dim3(128), 0, st, a);
 }
 void rc_launch_material_composite_all(int64_t n, int S, const float* weights, const float* mat, float* out_albedo,
                                       float* out_rough, float* out_metal, float* out_f0, float f0, hipStream_t st) {
