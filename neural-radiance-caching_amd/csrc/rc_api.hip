@@ -1544,7 +1544,11 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
   // fill the gaps of its latency-bound kernels.  Forked from and joined to the caller's stream with events: to the
   // caller the call is still ordered on `st` alone.
   if (!h->side_stream) {
-    RC_HIP(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    // lowest priority: what runs here (light sampler, material-only pass, EnvMap) only feeds the outputs and the step's
+    // last kernel; the kernels on the caller's stream -- the critical path -- get the CUs first
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    RC_HIP(h, hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio_lo));
     for (hipEvent_t& e : h->ev_side) RC_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   hipStream_t side = h->side_stream;

@@ -219,8 +219,29 @@ __global__ __launch_bounds__(256) void k_brdf_sample(RcBrdfSampleArgs a) {
   int64_t r = (int64_t)blockIdx.x * 4 + wave;
   const bool ok = r < a.n;
   if (!ok) r = a.n - 1;
-  for (int i = lane; i < 128 * RC_VMF_CH; i += 64) s_vmf[wave][i] = a.vmf[r * 128 * RC_VMF_CH + i];
-  for (int j = lane; j < 128; j += 64) s_den[wave][j] = 4.0f * kPi * sinhf(a.vmf[(r * 128 + j) * RC_VMF_CH + 3]);
+  // Every global read of the point that depends on nothing computed here is issued up front, in one batch: the lobe
+  // table (10 values per lane), the lobe logits + noise, the lane's own random inputs.  (As a loop of "load, store to
+  // LDS" the table alone was ten dependent round trips -- the loads were not hoisted over the LDS stores -- and the
+  // random inputs sat behind the barriers below: ~12 of this kernel's 37 us.)
+  const int Ks = a.Ks, Kd = a.Kd, Kc = a.Kc, K = Ks + Kd;
+  const int kd = lane - Ks, kl = kd - Kc, Kl = Kd - Kc;
+  static_assert(128 * RC_VMF_CH == 10 * 64, "lobe table: ten values per lane");
+  float tab[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) tab[k] = a.vmf[r * 128 * RC_VMF_CH + lane + 64 * k];
+  float lg[2] = {0.0f, 0.0f}, gm[2] = {0.0f, 0.0f};
+  if (!a.vmf_lobe) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { lg[q] = a.vmf_logit[r * 128 + lane + 64 * q]; gm[q] = a.vmf_lobe_gumbel[r * 128 + lane + 64 * q]; }
+  }
+  float ru1 = 0.0f, ru2 = 0.0f, rtmp = 0.0f;       // (u1, u2) of a GGX / cosine lane, (v0, v1) and tmp of a vMF lane
+  if (lane < Ks) { ru1 = a.spec_u1[r * Ks + lane]; ru2 = a.spec_u2[r * Ks + lane]; }
+  else if (lane < K && kd < Kc) { ru1 = a.cos_u1[r * Kc + kd]; ru2 = a.cos_u2[r * Kc + kd]; }
+  else if (lane < K) { ru1 = a.vmf_v[(r * Kl + kl) * 2]; ru2 = a.vmf_v[(r * Kl + kl) * 2 + 1]; rtmp = a.vmf_tmp[r * Kl + kl]; }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) s_vmf[wave][lane + 64 * k] = tab[k];
+  __syncthreads();
+  for (int j = lane; j < 128; j += 64) s_den[wave][j] = 4.0f * kPi * sinhf(s_vmf[wave][j * RC_VMF_CH + 3]);
   __syncthreads();
   const float* vm = s_vmf[wave];
   const float* den = s_den[wave];
@@ -236,7 +257,7 @@ __global__ __launch_bounds__(256) void k_brdf_sample(RcBrdfSampleArgs a) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int jj = lane + 64 * q;
-      const float kq = a.vmf_logit[r * 128 + jj] + a.vmf_lobe_gumbel[r * 128 + jj];
+      const float kq = lg[q] + gm[q];
       if (kq > key) { key = kq; best = jj; }
     }
 #pragma unroll
@@ -248,7 +269,6 @@ __global__ __launch_bounds__(256) void k_brdf_sample(RcBrdfSampleArgs a) {
     lobe = best;
   }
   lobe = min(max(lobe, 0), 127);
-  const int Ks = a.Ks, Kd = a.Kd, Kc = a.Kc, K = Ks + Kd;
   const V3 nrm = {a.nrm[3 * r], a.nrm[3 * r + 1], a.nrm[3 * r + 2]};
   const V3 pt = {a.pts[3 * r], a.pts[3 * r + 1], a.pts[3 * r + 2]};
   const V3 gview = {-a.viewdirs[3 * r], -a.viewdirs[3 * r + 1], -a.viewdirs[3 * r + 2]};
@@ -264,12 +284,11 @@ __global__ __launch_bounds__(256) void k_brdf_sample(RcBrdfSampleArgs a) {
   V3 ld = {0.0f, 0.0f, 1.0f};
   float pdf = 0.0f, weight = 0.0f, own_pdf = 0.0f;
   const bool live = lane < K && ok, diffuse = live && lane >= Ks;
-  const int kd = lane - Ks, kl = kd - Kc, Kl = Kd - Kc;
   const bool vmf_lane = diffuse && kd >= Kc;
   if (live) {
     if (lane < Ks) {
       // MicrofacetSampler.sample_directions (render_utils.py:501-531); single sampler -> weight 1
-      const float u1 = a.spec_u1[r * Ks + lane], u2 = a.spec_u2[r * Ks + lane];
+      const float u1 = ru1, u2 = ru2;
       const float tan2 = alpha * alpha * u1 / fmaxf(1.0f - u1, RC_EPS);
       const float cost = 1.0f / sqrtf(fmaxf(1.0f + tan2, RC_EPS));
       const float sint = sqrtf(fmaxf(kDenomEps, 1.0f - cost * cost));
@@ -286,7 +305,7 @@ __global__ __launch_bounds__(256) void k_brdf_sample(RcBrdfSampleArgs a) {
     } else {
       if (kd < Kc) {
         // CosineSampler (render_utils.py:425-433)
-        const float u1 = a.cos_u1[r * Kc + kd], u2 = a.cos_u2[r * Kc + kd];
+        const float u1 = ru1, u2 = ru2;
         const float rr = sqrtf(u1), phi = u2 * 2.0f * kPi - kPi;
         const float x = rr * cosf(phi), y = rr * sinf(phi);
         const float z = sqrtf(fmaxf(kDenomEps, 1.0f - x * x - y * y));
@@ -299,12 +318,12 @@ __global__ __launch_bounds__(256) void k_brdf_sample(RcBrdfSampleArgs a) {
         const float kappa = q[3];
         const V3 tv = l2_normalize(V3{-mean.y, mean.x, 0.0f});
         const V3 bv = l2_normalize(cross(mean, tv));
-        float v0 = a.vmf_v[(r * Kl + kl) * 2], v1 = a.vmf_v[(r * Kl + kl) * 2 + 1];
+        float v0 = ru1, v1 = ru2;
         {
           const float dsq = v0 * v0 + v1 * v1, l = sqrtf(fmaxf(RC_TINY, dsq));
           if (dsq < RC_TINY) { v0 = 0.0f; v1 = 0.0f; } else { v0 = v0 / l; v1 = v1 / l; }
         }
-        const float tmp = a.vmf_tmp[r * Kl + kl];
+        const float tmp = rtmp;
         const float arg = tmp + (1.0f - tmp) * expf(-2.0f * kappa);
         const float w = 1.0f + (1.0f / fmaxf(kappa, RC_EPS)) * logf(fminf(fmaxf(arg, RC_TINY), RC_FMAX));
         const float s = sqrtf(fminf(fmaxf(1.0f - w * w, 0.0f), RC_FMAX));
