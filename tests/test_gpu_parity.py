@@ -376,6 +376,50 @@ def test_secondary_rays_vs_oracle(rc):
     assert np.abs(out["distance_median"].cpu().numpy() - r["distance_median"].numpy()).max() <= 1e-3
 
 
+def test_power_ladder_mapping_of_the_secondary_rays_to_a_few_ulp_of_the_power(rc):
+    """s -> t of the secondary rays' fence posts = math.inv_power_ladder (internal/math.py:319-341) with p = -1.5: the
+    kernels evaluate its power with the hardware's log2 / exp2 around a split exponent (rc_dev_sample.h pow_pos) instead
+    of the library's powf.  From the kernel's own float32 fence posts in s (workspace sdist) a float64 evaluation of the
+    mapping must give the kernel's t with the power itself within 4 float32 ulp -- on all three levels, 512 rays."""
+    from nrc_amd import rc_ext
+    n = 512
+    rays, rnd = common.secondary_case(n, seed=15)
+    rays = {k: v for k, v in rays.items() if k != "normals"}          # no near replacement: one (near, far) for all rays
+    rc.render_rays(rays, rnd, rc_ext.RC_PASS_CACHE | rc_ext.RC_PASS_SECONDARY | rc_ext.RC_PASS_NO_ENVMAP, outputs=["rgb", "acc"])
+    torch.cuda.synchronize()
+    cfg = nrc_amd.hotdog_config()
+    p, premult = np.float32(cfg.raydist_p), np.float32(cfg.raydist_premult)
+    near = np.asarray(rays["near"], np.float32).reshape(-1)
+    far = np.minimum(np.asarray(rays["far"], np.float32).reshape(-1), np.float32(cfg.env_map_distance))
+
+    def ladder32(x):                                       # power_ladder in float32 as the kernel's k_ladder_bounds does
+        x = np.float32(x) * premult
+        xs = np.abs(x) / np.maximum(np.float32(1.17549435e-38), np.abs(p - np.float32(1)))
+        y = np.abs(p - np.float32(1)) / p * (np.power(xs + np.float32(1), p, dtype=np.float32) - np.float32(1))
+        return np.sign(x) * y
+
+    for l, S in enumerate((64, 64, 32)):
+        sd = rc.workspace(f"sdist{l}")[: n * (S + 1)].reshape(n, S + 1).astype(np.float64)
+        td = rc.workspace(f"tdist{l}")[: n * (S + 1)].reshape(n, S + 1)
+        # the rays of secondary_case share one (near, far): the bounds in s are two float32 numbers
+        s_near, s_far = np.float64(ladder32(near[0])), np.float64(ladder32(far[0]))
+        y = (sd * s_far + (1.0 - sd) * s_near).astype(np.float32).astype(np.float64)   # the kernel's float32 argument
+        p64, pm1 = np.float64(p), abs(np.float64(p) - 1.0)
+        c32 = np.float64(np.float32(1.0) / p)                                            # the exponent as float32, like the reference
+        x32 = (np.float32(p64 / pm1) * y.astype(np.float32) + np.float32(1)).astype(np.float64)
+        pw = np.power(x32, c32)
+        want = pm1 * (pw - 1.0) / np.float64(premult)
+        # t = pm1 (x^c - 1) / premult: an error of the power enters t in absolute terms (near t = 0 the subtraction cancels),
+        # so the budget is in ulp OF THE POWER scaled by pm1 / premult -- 4: pow_pos's ~1.5 plus the two bounds in s, which
+        # the kernel gets from the library's powf and this test from numpy's (each may differ by one ulp) -- plus 4 ulp of t
+        # for the float32 steps around the power (measured worst case over the three levels: 3.03 of the 4)
+        ulp_pw = np.spacing(pw.astype(np.float32)).astype(np.float64)
+        ulp_t = np.spacing(np.abs(want).astype(np.float32)).astype(np.float64)
+        err = np.abs(td.astype(np.float64) - want)
+        tol = 4.0 * ulp_pw * pm1 / np.float64(premult) + 4.0 * ulp_t
+        assert (err <= tol).all(), (l, float((err / tol).max()))
+
+
 def test_secondary_rays_without_envmap_and_given_indices(rc):
     from nrc_amd import rc_ext
     n = 200
