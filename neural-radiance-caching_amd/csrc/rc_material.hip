@@ -424,7 +424,9 @@ __global__ __launch_bounds__(256) void k_material_integrate(RcMatIntegrateArgs a
     const float D = ggx_d(n_h, rough);
     const float k = rough / 2.0f;
     const float G = (n_v / fmaxf(RC_EPS, n_v * (1.0f - k) + k)) * (n_l / fmaxf(RC_EPS, n_l * (1.0f - k) + k));
-    const float c5 = powf(fminf(fmaxf(1.0f - l_h, 0.0f), 1.0f), 5.0f);
+    // jnp.power(x, 5) with a static integer exponent is lax.integer_pow: x * (x^2)^2, three multiplies (render_utils.py:627)
+    const float c1 = fminf(fmaxf(1.0f - l_h, 0.0f), 1.0f), c2 = c1 * c1, c4 = c2 * c2;
+    const float c5 = c1 * c4;
     const float dl = fmaxf(0.0f, wi.z) / kPi;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {

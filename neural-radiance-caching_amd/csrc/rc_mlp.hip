@@ -53,10 +53,21 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
   ws_begin<NF>(ws);
 
   // stage the grid features (natural k pairs) + bias step
+  // (all loads first, from clamped -- always valid -- addresses, the selects behind them: as "condition ? load : 0" each
+  // of the up to 16 loads sat in its own branch with an s_waitcnt vmcnt(0) behind it, 16 dependent round trips)
+  {
+    float fv[KS0 - 1];
+    const int64_t pp = valid ? p : 0;
 #pragma unroll
-  for (int s = 0; s < KS0 - 1; ++s) {
-    const int k = 2 * s + h;
-    act[s * 64] = (valid && k < a.K) ? a.feat[(int64_t)k * a.ld + p] : 0.0f;
+    for (int s = 0; s < KS0 - 1; ++s) {
+      const int k = 2 * s + h;
+      fv[s] = a.feat[(int64_t)(k < a.K ? k : a.K - 1) * a.ld + pp];
+    }
+#pragma unroll
+    for (int s = 0; s < KS0 - 1; ++s) {
+      const int k = 2 * s + h;
+      act[s * 64] = (valid && k < a.K) ? fv[s] : 0.0f;
+    }
   }
   act[(KS0 - 1) * 64] = h == 0 ? 1.0f : 0.0f;
 

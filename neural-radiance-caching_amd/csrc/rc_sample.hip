@@ -121,7 +121,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
   for (int e2 = lane; e2 <= S; e2 += 64) s_t[e2] = a.tdist[ray * (S + 1) + e2];
   lds_sync<false>();
   const float t0 = act ? s_t[lane] : 1.0f, t1 = act ? s_t[lane + 1] : 1.0f;
-  const float dens = act ? a.density[pidx] : 0.0f;
+  // (loads from always-valid addresses, selects behind them: a `condition ? load : 0` becomes a branch around the load
+  // with a wait behind it, one dependent round trip per input)
+  const float dens_ld = a.density[pidx];
+  const float dens = act ? dens_ld : 0.0f;
   const float wnf = alpha_weight(dens, t0, t1, dnorm, act, lane);     // weights_no_filter
   if (act && ray_ok && a.weights) a.weights[pidx] = wnf;
   const float acc = wave_sum(wnf);                                    // render.py:202
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
   const int64_t nsh = resampled ? a.n_rays : np;
   const int64_t sidx = resampled ? ray : pidx;
 
-  auto shade = [&](int ch) -> float { return contrib ? a.shade[(int64_t)ch * nsh + sidx] : 0.0f; };
+  auto shade = [&](int ch) -> float { const float v = a.shade[(int64_t)ch * nsh + sidx]; return contrib ? v : 0.0f; };
   auto store3 = [&](int id, float x, float y, float z) {
     if (lane == 0 && ray_ok && a.out.ptr[id]) {
       a.out.ptr[id][3 * ray] = x; a.out.ptr[id][3 * ray + 1] = y; a.out.ptr[id][3 * ray + 2] = z;
@@ -158,8 +161,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
   const float wc = contrib ? w : 0.0f;
   const bool components = want(RC_OUT_DIRECT_RGB) || want(RC_OUT_INDIRECT_DIFFUSE_RGB) || want(RC_OUT_INDIRECT_SPECULAR_RGB) ||
                           want(RC_OUT_SPECULAR_RGB) || want(RC_OUT_ALBEDO_RGB) || want(RC_OUT_DIFFUSE_RGB) || want(RC_OUT_INDIRECT_RGB);
-  const bool pos = act && (components || want(RC_OUT_MEANS) || want(RC_OUT_RAY_DISTS) || want(RC_OUT_LIGHT_DISTS));
-  const float mx = pos ? a.means[pidx] : 0.0f, my = pos ? a.means[np + pidx] : 0.0f, mz = pos ? a.means[2 * np + pidx] : 0.0f;
+  const bool want_pos = components || want(RC_OUT_MEANS) || want(RC_OUT_RAY_DISTS) || want(RC_OUT_LIGHT_DISTS);      // uniform
+  const bool pos = act && want_pos;
+  float mx = 0.0f, my = 0.0f, mz = 0.0f;
+  if (want_pos) {
+    const float lx = a.means[pidx], ly = a.means[np + pidx], lz = a.means[2 * np + pidx];
+    mx = pos ? lx : 0.0f; my = pos ? ly : 0.0f; mz = pos ? lz : 0.0f;
+  }
   auto ray_dist = [&]() {
     const float ox = a.origins[3 * ray], oy = a.origins[3 * ray + 1], oz = a.origins[3 * ray + 2];
     return sqrtf((ox - mx) * (ox - mx) + (oy - my) * (oy - my) + (oz - mz) * (oz - mz));
@@ -190,8 +198,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
     v[V_LD] = a.lights ? wc * light_dist() : 0.0f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      v[V_NP + c] = a.normals_pred ? wc * (act ? a.normals_pred[c * np + pidx] : 0.0f) : 0.0f;
-      v[V_NG + c] = a.normals_grad ? wc * (act ? a.normals_grad[c * np + pidx] : 0.0f) : 0.0f;
+      float np_v = 0.0f, ng_v = 0.0f;
+      if (a.normals_pred) { const float l = a.normals_pred[c * np + pidx]; np_v = act ? l : 0.0f; }
+      if (a.normals_grad) { const float l = a.normals_grad[c * np + pidx]; ng_v = act ? l : 0.0f; }
+      v[V_NP + c] = a.normals_pred ? wc * np_v : 0.0f;
+      v[V_NG + c] = a.normals_grad ? wc * ng_v : 0.0f;
     }
     wave_sum_n<V_COUNT>(v);
     store3(RC_OUT_RGB, v[V_RGB] + bgw, v[V_RGB + 1] + bgw, v[V_RGB + 2] + bgw);

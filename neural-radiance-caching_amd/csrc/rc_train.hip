@@ -63,12 +63,22 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_bwd(RcDensityBwdArgs a)
   };
 
   // stage the grid features (natural k pairs) + bias step; keep a point-major copy for dW0
+  // (all loads first, from clamped addresses; see k_density_mlp)
+  {
+    float fv[KS0 - 1];
+    const int64_t pp = valid ? p : 0;
 #pragma unroll
-  for (int s = 0; s < KS0 - 1; ++s) {
-    const int k = 2 * s + h;
-    const float v = (valid && k < a.K) ? a.feat[(int64_t)k * a.ld + p] : 0.0f;
-    act[s * 64] = v;
-    if (valid) a.fe[p * 32 + k] = v;
+    for (int s = 0; s < KS0 - 1; ++s) {
+      const int k = 2 * s + h;
+      fv[s] = a.feat[(int64_t)(k < a.K ? k : a.K - 1) * a.ld + pp];
+    }
+#pragma unroll
+    for (int s = 0; s < KS0 - 1; ++s) {
+      const int k = 2 * s + h;
+      const float v = (valid && k < a.K) ? fv[s] : 0.0f;
+      act[s * 64] = v;
+      if (valid) a.fe[p * 32 + k] = v;
+    }
   }
   act[(KS0 - 1) * 64] = h == 0 ? 1.0f : 0.0f;
 

@@ -430,22 +430,26 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
   int win_lo = kBins, win_hi = -1;
   if (lane < 32) {
     const int64_t p = ray * 32 + lane;
-    const float ld = a.tshade[RC_TS_LDIST * n + p];
-    sp[P_W * 32 + lane] = a.weights[p];
+    // the eight per-sample inputs in one batch of loads (as "LDS slot = load" they were eight dependent round trips: the
+    // loads were not moved over the LDS stores between them)
+    const float ld = a.tshade[RC_TS_LDIST * n + p], in_w = a.weights[p], in_cam = a.tshade[RC_TS_CAMDIST * n + p];
+    const float in_t0 = a.tshade[(RC_TS_TIB + 0) * n + p], in_t1 = a.tshade[(RC_TS_TIB + 1) * n + p],
+                in_t2 = a.tshade[(RC_TS_TIB + 2) * n + p], in_rd = a.tshade[RC_TS_RDIST * n + p];
+    sp[P_W * 32 + lane] = in_w;
     sp[P_LDIST * 32 + lane] = ld;
-    sp[P_CAMDIST * 32 + lane] = a.tshade[RC_TS_CAMDIST * n + p];
-    sp[P_TIB0 * 32 + lane] = a.tshade[(RC_TS_TIB + 0) * n + p];
-    sp[P_TIB1 * 32 + lane] = a.tshade[(RC_TS_TIB + 1) * n + p];
-    sp[P_TIB2 * 32 + lane] = a.tshade[(RC_TS_TIB + 2) * n + p];
+    sp[P_CAMDIST * 32 + lane] = in_cam;
+    sp[P_TIB0 * 32 + lane] = in_t0;
+    sp[P_TIB1 * 32 + lane] = in_t1;
+    sp[P_TIB2 * 32 + lane] = in_t2;
     // bins_move / exposure_time (render.py:483): ray_dist + shift, divided by the exposure
-    sp[P_DIND * 32 + lane] = (a.tshade[RC_TS_RDIST * n + p] + a.shift) / a.exposure;
+    sp[P_DIND * 32 + lane] = (in_rd + a.shift) / a.exposure;
     const bool kill = a.light_zero && ld < a.light_near;                               // render_utils.py:1750-1760
     sp[P_KILL * 32 + lane] = kill ? 1.0f : 0.0f;
     // Window of bins that survive zero_invalid_bins (render_utils.py:1699-1767), once per sample (lane = sample).
     // Both travel-time tests are monotone in the bin index, so each is a bound: bins >= lo pass
     // "(b + thr) * e < light_dist" (too close), bins <= hi pass "b * e + cam_dist > max_dists" (too far); the bounds
     // are settled with the very comparisons of the reference.
-    const float cdist = sp[P_CAMDIST * 32 + lane];
+    const float cdist = in_cam;
     auto close = [&](int b) { return (float)(b + a.bin_zero_threshold_light) * a.exposure < ld; };
     auto far = [&](int b) { return ((float)b * a.exposure + cdist) > a.max_dists; };
     int lo = (int)ceilf(ld / a.exposure) - a.bin_zero_threshold_light;
