@@ -267,7 +267,16 @@ __device__ __forceinline__ void sample_level_ray(const RcSampleArgs& a, const US
     const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
     w = alpha_weight(dens, t0, t1, dnorm, act, lane);
     if (act && ray_ok && a.prev_weights) a.prev_weights[ray * P + lane] = w;
-    for (int e2 = lane; e2 <= P; e2 += 64) s_t[e2] = a.prev_sdist[ray * (P + 1) + e2];
+    {
+      // P + 1 <= 65 fence posts on 64 lanes: both loads of a lane issued before the LDS stores (as a loop the second pass,
+      // one lane, was a dependent round trip of its own)
+      const bool h0 = lane <= P, h1 = lane + 64 <= P;
+      float v0 = 0.0f, v1 = 0.0f;
+      if (h0) v0 = a.prev_sdist[ray * (P + 1) + lane];
+      if (h1) v1 = a.prev_sdist[ray * (P + 1) + lane + 64];
+      if (h0) s_t[lane] = v0;
+      if (h1) s_t[lane + 64] = v1;
+    }
   }
   const float logit = a.anneal * safe_log(w + a.padding);
   const bool hasj = a.jitter != nullptr;
