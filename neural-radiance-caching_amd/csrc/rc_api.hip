@@ -1018,6 +1018,10 @@ struct RenderArgs {
   const rc_randoms* shadow_rnd = nullptr; bool weights_only = false; bool force_grad = false;
   bool export_samples = false;     // fused plan: leave tdist / density / means / normals_pred of the last level in the workspace
   const float* s_bounds = nullptr; // secondary rays with ONE (near, far): power-ladder bounds computed once (RcSampleArgs)
+  // material stage: the EnvMap of the trace's directions is released on `env_side` when the LAST proposal level is
+  // launched, which leaves `env_reserve` CUs to it (both kernels keep a CU's LDS to themselves; see rc_render_material)
+  const RcEnvMapArgs* env = nullptr; hipStream_t env_side = nullptr; hipEvent_t env_ready = nullptr, env_done = nullptr;
+  int env_reserve = 0;
 };
 
 void enqueue_transient_tail(rc_handle* h, const RenderArgs& A, hipStream_t st);
@@ -1119,6 +1123,13 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     // (one ray per wave pays from ~100 rays per CU on: measured break-even of the whole pass near 32 k rays, +27 us at 1-4 k)
     if (level_kernel && (h->fused_mode == 1 || h->fused_mode == 3) && n >= 24576 && rc_level_ray_supported(h->grids[l].dev, S)) {
       roctx_stage(l == 0 ? "level0 (sample+grid+mlp)" : (l == 1 ? "level1 (sample+grid+mlp)" : "level2 (sample+grid+mlp)"));
+      if (A.env && l == NL - 1) {
+        (void)hipEventRecord(A.env_ready, st);
+        (void)hipStreamWaitEvent(A.env_side, A.env_ready, 0);
+        rc_launch_envmap(*A.env, A.env_side);
+        (void)hipEventRecord(A.env_done, A.env_side);
+        la.cu_reserve = A.env_reserve;
+      }
       rc_launch_level_ray(la, sa, st);
       continue;
     }
@@ -1629,15 +1640,25 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     memset(&B.out, 0, sizeof(B.out));
     B.out.ptr[RC_OUT_RGB] = W(h, "sec_rgb"); B.out.ptr[RC_OUT_ACC] = W(h, "sec_acc");
     float* sec_dirs = W(h, "sec_dirs"); float* sec_env = W(h, "sec_env");
-    // 6b. EnvMap of the secondary directions on the side stream, beside the first sampling kernel of the trace.
-    // (Released behind the last proposal level instead, it overlaps the pick and the per-pick lookups but holds the
-    // LDS the per-pick density MLP and the shader wait for: measured the same within noise.)
-    RC_HIP(h, hipEventRecord(h->ev_side[1], st));                 // secondary rays are in place
-    RC_HIP(h, hipStreamWaitEvent(side, h->ev_side[1], 0));
     RcEnvMapArgs ea{};
     ea.n = nsec; ea.viewdirs = sec_dirs; ea.wstream = h->packs["envmap"].p; ea.rgb_bias = c.env_rgb_bias; ea.env_rgb = sec_env;
-    rc_launch_envmap(ea, side);
-    RC_HIP(h, hipEventRecord(h->ev_side[2], side));
+    // 6b. EnvMap of the secondary directions, on the side stream.  It is MFMA-bound and keeps a CU's LDS to itself, as the
+    // level kernels of the trace do: next to a level kernel it only gets the CUs that kernel's persistent workgroups
+    // leave.  Beside the first two levels (F = 1: bound by their own instruction issue) every CU it takes is a CU they
+    // miss; the LAST level (F = 4) is bound by the fabric's random-sector rate, not by CUs.  So the EnvMap is released when
+    // that level is launched, and that launch leaves it a quarter of the CUs (RC_ENV_RESERVE overrides; 0 = beside the
+    // first level as before): 1.48 -> 1.45 ms per step (reserve 32 / 64 / 96 of 256: 1.463 / 1.447-1.456 / 1.508).
+    static const int env_reserve = getenv("RC_ENV_RESERVE") ? atoi(getenv("RC_ENV_RESERVE")) : rc_device_cus() / 4;
+    const bool beside_last = env_reserve > 0 && nsec >= 24576 && (h->fused_mode == 1 || h->fused_mode == 3);
+    if (beside_last) {
+      B.env = &ea; B.env_side = side; B.env_ready = h->ev_side[1]; B.env_done = h->ev_side[2]; B.env_reserve = env_reserve;
+      RC_HIP(h, hipEventRecord(h->ev_side[2], side));             // in case the trace takes another launch plan: join on what is there
+    } else {
+      RC_HIP(h, hipEventRecord(h->ev_side[1], st));               // secondary rays are in place
+      RC_HIP(h, hipStreamWaitEvent(side, h->ev_side[1], 0));
+      rc_launch_envmap(ea, side);
+      RC_HIP(h, hipEventRecord(h->ev_side[2], side));
+    }
     h->ws_prefix = "s:";
     enqueue_all(h, B, st);
     h->ws_prefix = "";

@@ -170,6 +170,7 @@ struct RcLevelArgs {
   const float* wstream;       // the level's "dens_<l>" fragment stream
   float density_bias, contract_radius;
   float* density;             // [n]
+  int cu_reserve = 0;         // CUs the launch leaves to a kernel released beside it (k_level_ray only)
 };
 bool rc_level_supported(const RcGridDev& g);
 void rc_launch_level(const RcLevelArgs& a, hipStream_t stream);

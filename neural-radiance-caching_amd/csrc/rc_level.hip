@@ -321,12 +321,13 @@ void launch_level(const RcLevelKArgs& a, hipStream_t stream) {
 }
 
 template <int F, int NL, int S, int ND>
-void launch_level_ray(const RcLevelRayKArgs& a, hipStream_t stream) {
+void launch_level_ray(const RcLevelRayKArgs& a, hipStream_t stream, int cu_reserve = 0) {
   using LK = LevelK<F, NL, ND>;
   constexpr int W = LK::W;
   const int lds = (LK::kResFloats + W * (kLvActSteps * 64)) * (int)sizeof(float);
   (void)prepare_level_ray<F, NL, S, ND>();
-  const int cus = rc_device_cus();
+  const int all = rc_device_cus();
+  const int cus = cu_reserve > 0 && cu_reserve < all ? all - cu_reserve : all;
   const int64_t want = (a.sa.n_rays + W - 1) / W;
   dim3 grid((unsigned)(want < cus ? want : cus)), block(W * 64);
   hipLaunchKernelGGL((k_level_ray<F, NL, S, ND>), grid, block, lds, stream, a);
@@ -378,7 +379,7 @@ void rc_launch_level_ray(const RcLevelArgs& A, const RcSampleArgs& sa, hipStream
   const bool ref = level_layout(a.lv.grid) == kRefDense;
   if (a.lv.grid.num_features == 1 && a.lv.grid.num_levels == 6) { if (ref) launch_level_ray<1, 6, 64, kRefDense>(a, stream); else launch_level_ray<1, 6, 64, -1>(a, stream); }
   else if (a.lv.grid.num_features == 1 && a.lv.grid.num_levels == 7) { if (ref) launch_level_ray<1, 7, 64, kRefDense>(a, stream); else launch_level_ray<1, 7, 64, -1>(a, stream); }
-  else if (a.lv.grid.num_features == 4 && a.lv.grid.num_levels == 8) launch_level_ray<4, 8, 32, -1>(a, stream);
+  else if (a.lv.grid.num_features == 4 && a.lv.grid.num_levels == 8) launch_level_ray<4, 8, 32, -1>(a, stream, A.cu_reserve);
 }
 
 void rc_launch_level(const RcLevelArgs& A, hipStream_t stream) {
