@@ -1575,9 +1575,8 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
         (void)hipStreamSynchronize(side);
     }
   } side_join{h, st, side, false};
-  // 3a. material head at the shading point (caller's stream) | 4. light sampler: 128 vMF lobes per shading point (side
-  // stream) -- both read only the shading point; then 3b. the material head on all samples and the material-only
-  // composite (side stream)
+  // 3a. material head and 4. light sampler (128 vMF lobes) at the shading point: one lookup launch + one head launch on the
+  // caller's stream; 3b. the material head on all samples and the material-only composite on the side stream
   roctx_stage("material: heads + light sampler");
   {
     RcMatHeadArgs ma{};
@@ -1587,25 +1586,24 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     RC_HIP(h, hipEventRecord(h->ev_side[0], st));                 // shading points, means / weights of the last level are in place
     RC_HIP(h, hipStreamWaitEvent(side, h->ev_side[0], 0));
     side_join.forked = true;
-    rc_launch_hashgrid(h->grids[5].dev, W(h, "m_pts"), 0, n, W(h, "l_feat"), 0, 32, c.contract_radius, nullptr, side);
     RcLightHeadArgs la{};
     la.n = n; la.feat = W(h, "l_feat");
     la.w0 = raw("params/LightSampler/layers_0", "kernel"); la.b0 = raw("params/LightSampler/layers_0", "bias");
     la.w1 = raw("params/LightSampler/layers_1", "kernel"); la.b1 = raw("params/LightSampler/layers_1", "bias");
     la.w2 = raw("params/LightSampler/output_layer", "kernel"); la.b2 = raw("params/LightSampler/output_layer", "bias");
     la.pts = W(h, "m_pts"); la.noise = mr->vmf_noise; la.vmf_scale = c.vmf_scale; la.vmf = W(h, "l_vmf"); la.vmf_logit = W(h, "l_vmf_logit");
-    rc_launch_light_head(la, side);
-    RC_HIP(h, hipEventRecord(h->ev_side[3], side));
+    // side stream: the material head on ALL samples and the material-only composite (outputs only)
     rc_launch_hashgrid(h->grids[4].dev, W(h, "means" + LL), 1, np2, W(h, "m_feat_all"), 0, 32, c.contract_radius, nullptr, side);
     ma.n = np2; ma.feat = W(h, "m_feat_all"); ma.mat = W(h, "m_mat_all");
     rc_launch_material_head(ma, side);
     rc_launch_material_composite_all(n, S2, W(h, "weights" + LL), W(h, "m_mat_all"), mat_out->ptr[RC_MOUT_MATERIAL_ALBEDO],
                                      mat_out->ptr[RC_MOUT_MATERIAL_ROUGHNESS], mat_out->ptr[RC_MOUT_MATERIAL_METALNESS],
                                      mat_out->ptr[RC_MOUT_MATERIAL_F_0], c.default_F_0, side);
-    rc_launch_hashgrid(h->grids[4].dev, W(h, "m_pts"), 0, n, W(h, "m_feat"), 0, 32, c.contract_radius, nullptr, st);
+    // caller's stream, the critical path: both grids at the shading points in one launch, both heads in one launch (as
+    // four launches on two streams the BRDF sampler waited ~12 us for the event behind the light head)
+    rc_launch_hashgrid_two(h->grids[4].dev, h->grids[5].dev, W(h, "m_pts"), n, W(h, "m_feat"), W(h, "l_feat"), c.contract_radius, st);
     ma.n = n; ma.feat = W(h, "m_feat"); ma.mat = W(h, "m_mat");
-    rc_launch_material_head(ma, st);
-    RC_HIP(h, hipStreamWaitEvent(st, h->ev_side[3], 0));          // the lobes
+    rc_launch_shading_heads(ma, la, st);
   }
   // 5. BRDF importance sampling -> secondary rays
   roctx_stage("material: brdf sample");

@@ -18,13 +18,10 @@ using namespace rcdev;
 namespace {
 
 template <int F, bool JAC>
-__global__ __launch_bounds__(256) void k_hashgrid_fwd(RcGridDev g, const float* __restrict__ pts, int soa_in,
-                                                        const int32_t* __restrict__ src, int64_t n_src,
-                                                        int64_t n, float* __restrict__ out, int feature_major,
-                                                        int64_t ldo, float contract_radius,
-                                                        float* __restrict__ jac) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int l = blockIdx.y;
+__device__ __forceinline__ void hashgrid_point(const RcGridDev& g, const float* __restrict__ pts, int soa_in,
+                                               const int32_t* __restrict__ src, int64_t n_src, int64_t n,
+                                               float* __restrict__ out, int feature_major, int64_t ldo,
+                                               float contract_radius, float* __restrict__ jac, int64_t p, int l) {
   if (p >= n) return;
   const int64_t q = src ? (int64_t)src[p] : p;
   float x, y, z;
@@ -64,6 +61,26 @@ __global__ __launch_bounds__(256) void k_hashgrid_fwd(RcGridDev g, const float* 
       jac[(int64_t)(2 * LF + l * F + f) * ldo + p] = gz * s;
     }
   }
+}
+
+template <int F, bool JAC>
+__global__ __launch_bounds__(256) void k_hashgrid_fwd(RcGridDev g, const float* __restrict__ pts, int soa_in,
+                                                        const int32_t* __restrict__ src, int64_t n_src,
+                                                        int64_t n, float* __restrict__ out, int feature_major,
+                                                        int64_t ldo, float contract_radius,
+                                                        float* __restrict__ jac) {
+  hashgrid_point<F, JAC>(g, pts, soa_in, src, n_src, n, out, feature_major, ldo, contract_radius, jac,
+                         (int64_t)blockIdx.x * 256 + threadIdx.x, blockIdx.y);
+}
+
+// Two F = 4 grids (any geometry) at the same row-major points in one launch: blockIdx.z picks the grid.  (The material and
+// the light grid at the 1024 shading points of a material step: two 8-us launches on two streams before.)
+__global__ __launch_bounds__(256) void k_hashgrid_two(RcGridDev ga, RcGridDev gb, const float* __restrict__ pts, int64_t n,
+                                                        float* __restrict__ out_a, float* __restrict__ out_b,
+                                                        float contract_radius) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.z == 0) { if ((int)blockIdx.y < ga.num_levels) hashgrid_point<4, false>(ga, pts, 0, nullptr, n, n, out_a, 0, 32, contract_radius, nullptr, p, blockIdx.y); }
+  else { if ((int)blockIdx.y < gb.num_levels) hashgrid_point<4, false>(gb, pts, 0, nullptr, n, n, out_b, 0, 32, contract_radius, nullptr, p, blockIdx.y); }
 }
 
 // Two F = 4 grids of identical level geometry looked up at the same points in ONE pass over their interleaved tables
@@ -132,4 +149,17 @@ void rc_launch_hashgrid_pair(const RcGridDev& g, const RcPairTables& pt, const f
   if (n <= 0) return;
   dim3 grid((unsigned)((n + 127) / 128), (unsigned)g.num_levels), block(256);
   hipLaunchKernelGGL(k_hashgrid_pair, grid, block, 0, stream, g, pt, points_soa, src, n_src, n, out_a, out_b, ldo, contract_radius);
+}
+
+void rc_launch_hashgrid_two(const RcGridDev& ga, const RcGridDev& gb, const float* points, int64_t n, float* out_a, float* out_b,
+                            float contract_radius, hipStream_t stream) {
+  if (n <= 0) return;
+  if (ga.num_features != 4 || gb.num_features != 4) {
+    rc_launch_hashgrid(ga, points, 0, n, out_a, 0, ga.num_levels * ga.num_features, contract_radius, nullptr, stream);
+    rc_launch_hashgrid(gb, points, 0, n, out_b, 0, gb.num_levels * gb.num_features, contract_radius, nullptr, stream);
+    return;
+  }
+  const int levels = ga.num_levels > gb.num_levels ? ga.num_levels : gb.num_levels;
+  hipLaunchKernelGGL(k_hashgrid_two, dim3((unsigned)((n + 255) / 256), (unsigned)levels, 2u), dim3(256), 0, stream, ga, gb, points, n,
+                     out_a, out_b, contract_radius);
 }

@@ -52,6 +52,9 @@ struct RcPairTables { const float* t[RC_MAX_GRID_LEVELS]; };
 void rc_launch_hashgrid_pair(const RcGridDev& g, const RcPairTables& pt, const float* points_soa, const int32_t* src,
                              int64_t n_src, int64_t n, float* out_a, float* out_b, int64_t ldo, float contract_radius,
                              hipStream_t stream);
+// two F = 4 grids looked up at the same row-major [n,3] points in one launch (row-major [n, L*4] outputs)
+void rc_launch_hashgrid_two(const RcGridDev& ga, const RcGridDev& gb, const float* points, int64_t n, float* out_a, float* out_b,
+                            float contract_radius, hipStream_t stream);
 void rc_launch_hashgrid(const RcGridDev& g, const float* points, int soa_in, int64_t n, float* out,
                         int feature_major, int64_t ldo, float contract_radius, float* jac_out,
                         hipStream_t stream);
@@ -232,6 +235,7 @@ struct RcLightHeadArgs {
   float* vmf_logit;                    // [n,128]: the lobe logits as the softmax sees them (the categorical lobe draw takes these)
 };
 void rc_launch_light_head(const RcLightHeadArgs& a, hipStream_t st);
+void rc_launch_shading_heads(const RcMatHeadArgs& m, const RcLightHeadArgs& l, hipStream_t st);     // both in one launch
 
 struct RcBrdfSampleArgs {
   int64_t n; int32_t Ks, Kd, Kc;

@@ -84,9 +84,9 @@ __device__ __forceinline__ float ggx_d(float c, float a) {
 // MH_PTS: 16 for large batches; 4 for the 1024 shading points of a material step (256 workgroups instead of 64: that
 // call sits on the step's critical path and is latency, not traffic).
 template <int MH_PTS>
-__global__ __launch_bounds__(128) void k_material_head(RcMatHeadArgs a) {
+__device__ __forceinline__ void material_head_block(const RcMatHeadArgs& a, int64_t block) {
   __shared__ float s_feat[MH_PTS][32], s_h[MH_PTS][128], s_out[MH_PTS][10];
-  const int64_t p0 = (int64_t)blockIdx.x * MH_PTS;
+  const int64_t p0 = block * MH_PTS;
   const int np = (int)((a.n - p0) < MH_PTS ? (a.n - p0) : MH_PTS);
   const int t = threadIdx.x;
   for (int e = t; e < np * 32; e += 128) s_feat[e >> 5][e & 31] = a.feat[p0 * 32 + e];
@@ -118,6 +118,8 @@ __global__ __launch_bounds__(128) void k_material_head(RcMatHeadArgs a) {
     m[4] = sigmoidf(so[8] + 0.0f);                                                                  // metalness
   }
 }
+template <int MH_PTS>
+__global__ __launch_bounds__(128) void k_material_head(RcMatHeadArgs a) { material_head_block<MH_PTS>(a, blockIdx.x); }
 
 // Composite of the material-only pass over all samples (models.py:1845-1912): sum_s w_s * mat_s.
 __global__ void k_material_composite_all(int64_t n, int S, const float* weights, const float* mat, float* out_albedo,
@@ -141,9 +143,8 @@ __global__ void k_material_composite_all(int64_t n, int S, const float* weights,
 // Light head: grid features (32) -> 64 -> 64 -> 640 -> 128 vMF lobes (normalised mean, kappa,
 // softmax weight, normalisation kappa / (4 pi sinh kappa))
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_light_head(RcLightHeadArgs a) {
+__device__ __forceinline__ void light_head_point(const RcLightHeadArgs& a, int64_t p) {
   __shared__ float s_x[32], s_h0[64], s_h1[64], s_p[640], s_red[128];
-  const int64_t p = blockIdx.x;
   const int t = threadIdx.x;
   if (t < 32) s_x[t] = a.feat[p * 32 + t];
   __syncthreads();
@@ -198,6 +199,15 @@ __global__ __launch_bounds__(128) void k_light_head(RcLightHeadArgs a) {
   float* o = a.vmf + (p * 128 + t) * RC_VMF_CH;
   o[0] = m.x; o[1] = m.y; o[2] = m.z; o[3] = kappa; o[4] = wgt;
   a.vmf_logit[p * 128 + t] = logit;
+}
+__global__ __launch_bounds__(128) void k_light_head(RcLightHeadArgs a) { light_head_point(a, blockIdx.x); }
+
+// The two heads at the shading points of a material step in ONE launch: blocks [0, mat_blocks) run the material head
+// (4 points each), the others the light head (one point each).  Both read only the shading point and feed the BRDF
+// sampler; as two launches on two streams the sampler waited 12 us for the cross-stream event behind them.
+__global__ __launch_bounds__(128) void k_shading_heads(RcMatHeadArgs m, RcLightHeadArgs l, int mat_blocks) {
+  if ((int)blockIdx.x < mat_blocks) material_head_block<4>(m, blockIdx.x);
+  else light_head_point(l, (int64_t)blockIdx.x - mat_blocks);
 }
 
 // eval_vmf (render_utils.py:1335-1347) with inverse_render.math.safe_exp = exp(min(x, 80))
@@ -518,6 +528,11 @@ void rc_launch_material_composite_all(int64_t n, int S, const float* weights, co
   if (n <= 0) return;
   hipLaunchKernelGGL(k_material_composite_all, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, S, weights, mat,
                      out_albedo, out_rough, out_metal, out_f0, f0);
+}
+void rc_launch_shading_heads(const RcMatHeadArgs& m, const RcLightHeadArgs& l, hipStream_t st) {
+  if (m.n <= 0 || l.n <= 0) { rc_launch_material_head(m, st); rc_launch_light_head(l, st); return; }
+  const int mat_blocks = (int)((m.n + 3) / 4);
+  hipLaunchKernelGGL(k_shading_heads, dim3((unsigned)(mat_blocks + l.n)), dim3(128), 0, st, m, l, mat_blocks);
 }
 void rc_launch_light_head(const RcLightHeadArgs& a, hipStream_t st) {
   if (a.n <= 0) return;
