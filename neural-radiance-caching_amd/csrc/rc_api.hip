@@ -1576,29 +1576,19 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     }
   } side_join{h, st, side, false};
   // 3a. material head and 4. light sampler (128 vMF lobes) at the shading point: one lookup launch + one head launch on the
-  // caller's stream; 3b. the material head on all samples and the material-only composite on the side stream
+  // caller's stream
   roctx_stage("material: heads + light sampler");
   {
     RcMatHeadArgs ma{};
     ma.w0 = raw("params/MaterialShader/bottleneck_layer", "kernel"); ma.b0 = raw("params/MaterialShader/bottleneck_layer", "bias");
     ma.w1 = raw("params/MaterialShader/pred_brdf_layer", "kernel"); ma.b1 = raw("params/MaterialShader/pred_brdf_layer", "bias");
     ma.min_roughness = c.min_roughness;
-    RC_HIP(h, hipEventRecord(h->ev_side[0], st));                 // shading points, means / weights of the last level are in place
-    RC_HIP(h, hipStreamWaitEvent(side, h->ev_side[0], 0));
-    side_join.forked = true;
     RcLightHeadArgs la{};
     la.n = n; la.feat = W(h, "l_feat");
     la.w0 = raw("params/LightSampler/layers_0", "kernel"); la.b0 = raw("params/LightSampler/layers_0", "bias");
     la.w1 = raw("params/LightSampler/layers_1", "kernel"); la.b1 = raw("params/LightSampler/layers_1", "bias");
     la.w2 = raw("params/LightSampler/output_layer", "kernel"); la.b2 = raw("params/LightSampler/output_layer", "bias");
     la.pts = W(h, "m_pts"); la.noise = mr->vmf_noise; la.vmf_scale = c.vmf_scale; la.vmf = W(h, "l_vmf"); la.vmf_logit = W(h, "l_vmf_logit");
-    // side stream: the material head on ALL samples and the material-only composite (outputs only)
-    rc_launch_hashgrid(h->grids[4].dev, W(h, "means" + LL), 1, np2, W(h, "m_feat_all"), 0, 32, c.contract_radius, nullptr, side);
-    ma.n = np2; ma.feat = W(h, "m_feat_all"); ma.mat = W(h, "m_mat_all");
-    rc_launch_material_head(ma, side);
-    rc_launch_material_composite_all(n, S2, W(h, "weights" + LL), W(h, "m_mat_all"), mat_out->ptr[RC_MOUT_MATERIAL_ALBEDO],
-                                     mat_out->ptr[RC_MOUT_MATERIAL_ROUGHNESS], mat_out->ptr[RC_MOUT_MATERIAL_METALNESS],
-                                     mat_out->ptr[RC_MOUT_MATERIAL_F_0], c.default_F_0, side);
     // caller's stream, the critical path: both grids at the shading points in one launch, both heads in one launch (as
     // four launches on two streams the BRDF sampler waited ~12 us for the event behind the light head)
     rc_launch_hashgrid_two(h->grids[4].dev, h->grids[5].dev, W(h, "m_pts"), n, W(h, "m_feat"), W(h, "l_feat"), c.contract_radius, st);
@@ -1619,6 +1609,25 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     sa.sec_far = W(h, "sec_far"); sa.sec_lights = W(h, "sec_lights"); sa.samples = W(h, "sec_samples");
     sa.local_view = W(h, "m_local_view");
     rc_launch_brdf_sample(sa, st);
+  }
+  // 3b. side stream: the material head on ALL samples and the material-only composite (outputs only).  Forked HERE, behind
+  // the BRDF sampler: beside the small latency-bound kernels above they doubled those kernels' times (heads 18 -> 35 us,
+  // sampler 19 -> 33 us); beside the first level of the trace they fit into what its workgroups leave of a CU (no LDS /
+  // 11 KB) and cost it little.
+  {
+    RC_HIP(h, hipEventRecord(h->ev_side[0], st));
+    RC_HIP(h, hipStreamWaitEvent(side, h->ev_side[0], 0));
+    side_join.forked = true;
+    RcMatHeadArgs ma{};
+    ma.w0 = raw("params/MaterialShader/bottleneck_layer", "kernel"); ma.b0 = raw("params/MaterialShader/bottleneck_layer", "bias");
+    ma.w1 = raw("params/MaterialShader/pred_brdf_layer", "kernel"); ma.b1 = raw("params/MaterialShader/pred_brdf_layer", "bias");
+    ma.min_roughness = c.min_roughness;
+    rc_launch_hashgrid(h->grids[4].dev, W(h, "means" + LL), 1, np2, W(h, "m_feat_all"), 0, 32, c.contract_radius, nullptr, side);
+    ma.n = np2; ma.feat = W(h, "m_feat_all"); ma.mat = W(h, "m_mat_all");
+    rc_launch_material_head(ma, side);
+    rc_launch_material_composite_all(n, S2, W(h, "weights" + LL), W(h, "m_mat_all"), mat_out->ptr[RC_MOUT_MATERIAL_ALBEDO],
+                                     mat_out->ptr[RC_MOUT_MATERIAL_ROUGHNESS], mat_out->ptr[RC_MOUT_MATERIAL_METALNESS],
+                                     mat_out->ptr[RC_MOUT_MATERIAL_F_0], c.default_F_0, side);
   }
   // 6. ONE batched secondary trace through the cache (is_secondary, resample, use_env_map=False;
   //    ref_rays.normals = None since MaterialMLP.shadow_eps_indirect = False) + EnvMap along the same rays
