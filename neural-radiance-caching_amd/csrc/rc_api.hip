@@ -1022,6 +1022,7 @@ struct RenderArgs {
   // launched, which leaves `env_reserve` CUs to it (both kernels keep a CU's LDS to themselves; see rc_render_material)
   const RcEnvMapArgs* env = nullptr; hipStream_t env_side = nullptr; hipEvent_t env_ready = nullptr, env_done = nullptr;
   int env_reserve = 0;
+  bool* env_released = nullptr;    // set when the launch plan taken had the spot (the caller releases the EnvMap itself otherwise)
 };
 
 void enqueue_transient_tail(rc_handle* h, const RenderArgs& A, hipStream_t st);
@@ -1129,6 +1130,7 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
         rc_launch_envmap(*A.env, A.env_side);
         (void)hipEventRecord(A.env_done, A.env_side);
         la.cu_reserve = A.env_reserve;
+        if (A.env_released) *A.env_released = true;
       }
       rc_launch_level_ray(la, sa, st);
       continue;
@@ -1657,18 +1659,28 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     // first level as before): 1.48 -> 1.45 ms per step (reserve 32 / 64 / 96 of 256: 1.463 / 1.447-1.456 / 1.508).
     static const int env_reserve = getenv("RC_ENV_RESERVE") ? atoi(getenv("RC_ENV_RESERVE")) : rc_device_cus() / 4;
     const bool beside_last = env_reserve > 0 && nsec >= 24576 && (h->fused_mode == 1 || h->fused_mode == 3);
+    bool env_released = false;
     if (beside_last) {
       B.env = &ea; B.env_side = side; B.env_ready = h->ev_side[1]; B.env_done = h->ev_side[2]; B.env_reserve = env_reserve;
-      RC_HIP(h, hipEventRecord(h->ev_side[2], side));             // in case the trace takes another launch plan: join on what is there
+      B.env_released = &env_released;
     } else {
       RC_HIP(h, hipEventRecord(h->ev_side[1], st));               // secondary rays are in place
       RC_HIP(h, hipStreamWaitEvent(side, h->ev_side[1], 0));
       rc_launch_envmap(ea, side);
       RC_HIP(h, hipEventRecord(h->ev_side[2], side));
+      env_released = true;
     }
     h->ws_prefix = "s:";
     enqueue_all(h, B, st);
     h->ws_prefix = "";
+    if (!env_released) {
+      // the trace took a launch plan without that spot (per-stage profiling on, a grid layout the level kernels do not
+      // cover): the EnvMap behind the trace
+      RC_HIP(h, hipEventRecord(h->ev_side[1], st));
+      RC_HIP(h, hipStreamWaitEvent(side, h->ev_side[1], 0));
+      rc_launch_envmap(ea, side);
+      RC_HIP(h, hipEventRecord(h->ev_side[2], side));
+    }
     RC_HIP(h, hipStreamWaitEvent(st, h->ev_side[2], 0));          // join: everything of this call is ordered on st again
     side_join.forked = false;
   }

@@ -321,3 +321,28 @@ def test_pick_composite_equals_the_general_composite():
         torch.cuda.synchronize()
         assert torch.equal(a["rgb"], b["rgb"]) and torch.equal(a["acc"], b["acc"]), mask
         assert float(a["rgb"].abs().sum()) > 0.0 and float(a["acc"].sum()) > 0.0
+
+
+@pytest.mark.gpu
+def test_material_stage_with_per_stage_profiling_on_takes_the_envmap_along():
+    """The EnvMap of the secondary trace is released where the LAST level kernel of the trace is launched.  With per-stage
+    profiling on the trace runs one kernel per stage -- a plan without that spot -- and the stage must release the EnvMap
+    itself: same outputs as without profiling, bit for bit (768 primary rays = 24 576 secondary rays)."""
+    from oracle import material_ref
+    from nrc_amd import rc_ext
+    cfg = nrc_amd.hotdog_config()
+    rc = rc_ext.RadianceCache(cfg, 0)
+    rc.load_weights(common.weights_material_np(False))
+    n = 768
+    rays = nrc_amd.synthetic_rays(n, seed=5)
+    rnd = material_ref.draw_randoms(cfg, n, seed=8)
+    res = []
+    for prof in (0, 1, 0):
+        rc.set_profiling(prof)
+        cres, mres = rc.render_material(rays.hot_fields(), rnd)
+        torch.cuda.synchronize()
+        res.append({**{"c:" + k: v.clone() for k, v in cres.items()}, **{"m:" + k: v.clone() for k, v in mres.items()}})
+    rc.set_profiling(0)
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]) and torch.equal(res[0][k], res[2][k]), k
+    assert any(float(v.abs().sum()) > 0 for k, v in res[0].items() if k.startswith("m:"))
