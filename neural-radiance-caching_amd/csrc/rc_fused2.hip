@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
   };
   auto density_of = [&](float raw, float cx, float cy, float cz, float bbox) {
     const bool inside = (cx > -bbox) & (cx < bbox) & (cy > -bbox) & (cy < bbox) & (cz > -bbox) & (cz < bbox);
-    const float d = expf(fminf(fmaxf(raw + a.density_bias, -RC_FMAX), 70.0f));
+    const float d = rc_safe_exp(raw + a.density_bias);
     return inside ? d : 0.0f;
   };
   const int j = lane & 31, h = lane >> 5;
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
     store3(RC_OUT_NORMALS_PRED, v[V_NP], v[V_NP + 1], v[V_NP + 2]);
     const float e = v[V_LOGT] / fmaxf(RC_EPS, accw);
     float dm = expf(e);
-    if (dm != dm) dm = INFINITY;
+    if (dm != dm) dm = 0.0f;                     // nan_to_num(x, copy=inf): nan -> 0.0 (rc_sample.hip, k_composite)
     dm = fminf(dm, RC_FMAX);
     dm = fminf(fmaxf(dm, s_td[0]), s_td[32]);
     store1(RC_OUT_DISTANCE_MEAN, dm);

@@ -23,6 +23,13 @@ __device__ __forceinline__ float rc_div(float x, float d) {
 #define RC_FMAX 3.40282347e+38f
 #define RC_EPS 1.1920929e-07f
 
+// math.safe_exp (internal/math.py:186-192): exp(jnp.clip(x, finfo.min, 70)).  jnp.clip = minimum(maximum(x, lo), hi) and
+// both PROPAGATE a NaN (v_max_f32 / v_min_f32 return the other operand): selects on ordered compares keep the NaN, so a
+// NaN raw density stays NaN as in the reference (oracle/JAX_CALLS.md, row `jnp.clip`).
+__device__ __forceinline__ float rc_safe_exp(float x) {
+  return expf(x > 70.0f ? 70.0f : (x < -RC_FMAX ? -RC_FMAX : x));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Hash grid
 // ---------------------------------------------------------------------------------------------

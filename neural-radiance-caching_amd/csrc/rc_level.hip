@@ -211,7 +211,7 @@ struct LevelK {
     dot_out1<2, 1, F_DO, NF, false, W, NOB, CH>(ws, acc, out, nokeep);     // output_density_layer on relu(acc)
     // convert_raw_density (geometry.py:318-341)
     const bool inside = (cx > -bbox) & (cx < bbox) & (cy > -bbox) & (cy < bbox) & (cz > -bbox) & (cz < bbox);
-    const float d = expf(fminf(fmaxf(out[0] + density_bias, -RC_FMAX), 70.0f));
+    const float d = rc_safe_exp(out[0] + density_bias);
     lds_sync_wave();        // the next tile's feature writes must not overtake this tile's activation reads
     return inside ? d : 0.0f;
   }

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
     // convert_raw_density (geometry.py:318-341)
     const float raw = out[0];
     const bool inside = (cx > -a.bbox) & (cx < a.bbox) & (cy > -a.bbox) & (cy < a.bbox) & (cz > -a.bbox) & (cz < a.bbox);
-    const float d = expf(fminf(fmaxf(raw + a.density_bias, -RC_FMAX), 70.0f));
+    const float d = rc_safe_exp(raw + a.density_bias);
     a.density[p] = inside ? d : 0.0f;
     if (NO == 4 && a.last && a.normals_pred) {
       float gx = out[NO > 1 ? 1 : 0], gy = out[NO > 2 ? 2 : 0], gz = out[NO > 3 ? 3 : 0];

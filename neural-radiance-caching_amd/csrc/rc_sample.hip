@@ -251,8 +251,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_composite(RcCompositeAr
     const float tmid = 0.5f * (t0 + t1);
     const float e = wave_sum(act ? wnf * logf(tmid) : 0.0f) / fmaxf(RC_EPS, acc);
     float dm = expf(e);
-    if (dm != dm) dm = INFINITY;                 // nan_to_num(nan=inf)
-    dm = fminf(dm, RC_FMAX);                     // +inf -> finfo.max
+    // render.py:233-237 `jnp.nan_to_num(x, jnp.inf)`: the second positional parameter of jax 0.4.16's nan_to_num is
+    // `copy`, so nan keeps its default 0.0 (then the clip lifts it to tdist[0]); +inf -> finfo.max (oracle/JAX_CALLS.md)
+    if (dm != dm) dm = 0.0f;
+    dm = fminf(dm, RC_FMAX);
     dm = fminf(fmaxf(dm, s_t[0]), s_t[S]);
     store1(RC_OUT_DISTANCE_MEAN, dm);
     const float wn = wnf / fmaxf(RC_EPS, acc);

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_bwd(RcDensityBwdArgs a)
     }
     const bool inside = (cx > -a.bbox) & (cx < a.bbox) & (cy > -a.bbox) & (cy < a.bbox) & (cz > -a.bbox) & (cz < a.bbox);
     const float x = out[0] + a.density_bias;
-    const float d = inside ? expf(fminf(fmaxf(x, -RC_FMAX), 70.0f)) : 0.0f;
+    const float d = inside ? rc_safe_exp(x) : 0.0f;
     // math.safe_exp is a custom_jvp (internal/math.py:153-171, 186-192): y_dot = y x_dot with the CLIPPED y, i.e. the
     // clip does not gate the gradient; jnp.where(valid, density, 0) does
     if (valid) g = a.d_density[p] * d;

@@ -320,7 +320,9 @@ def volume_integrate(cfg, shader_results, bg):
     expect = (wnf * torch.log(t_mids)).sum(-1) / torch.clamp(acc, min=eps)
     dm = torch.exp(expect)
     fi = torch.finfo(dm.dtype)
-    dm = torch.nan_to_num(dm, nan=float("inf"), posinf=fi.max, neginf=fi.min)
+    # render.py:233-237 / :308 write jnp.nan_to_num(x, jnp.inf): the 2nd positional parameter of jax 0.4.16's
+    # nan_to_num(x, copy=True, nan=0.0, posinf=None, neginf=None) is `copy` -> nan stays at its default 0.0
+    dm = torch.nan_to_num(dm, nan=0.0, posinf=fi.max, neginf=fi.min)
     r["distance_mean"] = torch.minimum(torch.maximum(dm, tdist[..., 0]), tdist[..., -1])
     pct = stepfun_ref.weighted_percentile(tdist, wnf_norm, cfg.percentiles)
     for i, p in enumerate(cfg.percentiles):

@@ -380,7 +380,8 @@ def integrate(cfg, per_sample, w_shade, w_all, tdist, bg):
     mids = 0.5 * (tdist[:, :-1] + tdist[:, 1:])
     with np.errstate(invalid="ignore", divide="ignore"):
         dm = np.exp((w_all * np.log(mids)).sum(axis=-1) / np.maximum(EPS, acc))
-    dm = np.where(np.isnan(dm), np.inf, dm)
+    # jnp.nan_to_num(x, jnp.inf): jnp.inf binds to `copy` (jax 0.4.16 signature), so NaN -> 0.0 and +-inf -> +-finfo.max
+    dm = nan0(dm)
     out["distance_mean"] = np.clip(dm, tdist[:, 0], tdist[:, -1])
     wn = w_all / np.maximum(EPS, acc)[:, None]
     pct = np.stack([percentiles_ray(tdist[r], wn[r], cfg.percentiles) for r in range(tdist.shape[0])])

@@ -1074,3 +1074,36 @@ def test_transient_fused_front_end_equals_the_staged_one(occ):
     torch.cuda.synchronize()
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_nan_density_distance_mean_is_first_fence_post():
+    """oracle/JAX_CALLS.md N1 + N3 on the device: a NaN `output_density_layer` bias on the last level makes every density
+    of that level NaN (math.safe_exp's jnp.clip propagates it), hence the weights and the log-distance expectation;
+    `jnp.nan_to_num(x, jnp.inf)` (render.py:233-237: jnp.inf binds to `copy`) turns that into 0.0 and the clip lifts it
+    to tdist[..., 0] -- not to tdist[..., -1], which the `nan=inf` reading of rounds 1-3 produced.  All three launch
+    plans (two-wave fused, launch-per-stage, one-wave fused) and the oracle."""
+    from nrc_amd import rc_ext
+    from oracle import cache_ref
+    n = 70
+    cfg = nrc_amd.hotdog_config()
+    w = dict(common.weights_np())
+    key = "params/Cache/Sampler/MLP_2/output_density_layer/bias"
+    w[key] = np.full_like(w[key], np.nan)
+    h = rc_ext.RadianceCache(cfg, 0)
+    h.load_weights(w)
+    rays = nrc_amd.synthetic_rays(n)
+    ref = cache_ref.cache_forward(common.to_torch(w), cfg, common.rays_torch(rays), None, want_grad_normals=False)
+    td_ref = ref["sampler"][-1]["tdist"].numpy()
+    assert np.array_equal(ref["render"]["distance_mean"].numpy(), td_ref[:, 0])
+    for plan in (1, 0, 3):
+        h.set_fused(plan)
+        out = h.render_rays(rays.hot_fields(), None, outputs=["distance_mean", "acc", "rgb"])
+        torch.cuda.synchronize()
+        dm = out["distance_mean"].cpu().numpy()
+        assert np.isnan(out["acc"].cpu().numpy()).all(), plan           # the NaN really reached the integrator
+        if plan == 0:
+            td = h.workspace("tdist2").reshape(n, 33)
+            assert np.array_equal(dm, td[:, 0]), plan
+            assert np.abs(td - td_ref).max() <= 1e-4
+        assert np.isfinite(dm).all() and np.abs(dm - td_ref[:, 0]).max() <= 1e-4, plan
+        assert (dm < td_ref[:, -1] - 0.1).all(), plan                  # the old reading gave the last fence post

@@ -267,3 +267,57 @@ def test_dead_cache_envmap_contributes_exact_zero():
     b = common.oracle_cache(8, dtype=F64, exec_dead_envmap=True, want_grad_normals=False)["render"]
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+# ---------------------------------------------------------------------------------------------
+# distance_mean: jnp.nan_to_num(x, jnp.inf) binds jnp.inf to `copy` (oracle/JAX_CALLS.md, N1; render.py:233-237, :308)
+# ---------------------------------------------------------------------------------------------
+def _nan_case():
+    """Two rays x four samples: ray 0 has a NaN weight (a poisoned density), ray 1 is ordinary."""
+    tdist = np.array([[2.0, 3.0, 4.0, 5.0, 6.0], [2.5, 3.0, 4.0, 5.0, 5.5]])
+    w = np.array([[0.1, np.nan, 0.2, 0.1], [0.1, 0.4, 0.2, 0.1]])
+    rgb = np.full((2, 4, 3), 0.5)
+    return tdist, w, rgb
+
+
+def test_distance_mean_nan_goes_to_first_fence_post():
+    """By hand: exp(NaN) = NaN -> nan_to_num(copy=inf) -> 0.0 -> clip(0, tdist[0], tdist[-1]) = tdist[0].  The reading
+    `nan=inf` (rounds 1-3) would give tdist[-1].  Ordinary ray: exp(sum w log t_mid / acc), inside the fence posts."""
+    from oracle import spec_np, transient_ref  # noqa: F401  (transient_integrate shares the statement, checked below)
+    tdist, w, rgb = _nan_case()
+    cfg = nrc_amd.hotdog_config()
+    expect1 = math.exp(sum(wi * math.log(0.5 * (a + b)) for wi, a, b in zip(w[1], tdist[1, :-1], tdist[1, 1:])) / w[1].sum())
+    for dt in (torch.float64, torch.float32):
+        sh = dict(weights=torch.tensor(w, dtype=dt), weights_no_filter=torch.tensor(w, dtype=dt),
+                  tdist=torch.tensor(tdist, dtype=dt), rgb=torch.tensor(rgb, dtype=dt))
+        r = cache_ref.volume_integrate(cfg, sh, 1.0)
+        assert float(r["distance_mean"][0]) == 2.0                       # tdist[0, 0], NOT tdist[0, -1] = 6
+        assert abs(float(r["distance_mean"][1]) - expect1) < 1e-5
+    out = spec_np.integrate(cfg, {"rgb": rgb}, w, w, tdist, 1.0)
+    assert out["distance_mean"][0] == 2.0
+    assert abs(out["distance_mean"][1] - expect1) < 1e-12
+    # +inf expectation -> finfo.max -> clipped to the LAST fence post (posinf default), in all witnesses
+    w_inf = np.array([[0.5, 0.5, 0.0, 0.0]])
+    t_inf = np.array([[1e30, 2e38, 3e38, 3.2e38, 3.3e38]])
+    sh = dict(weights=torch.tensor(w_inf, dtype=torch.float32), weights_no_filter=torch.tensor(w_inf, dtype=torch.float32),
+              tdist=torch.tensor(t_inf, dtype=torch.float32), rgb=torch.zeros(1, 4, 3))
+    r = cache_ref.volume_integrate(cfg, sh, 1.0)
+    assert torch.isfinite(r["distance_mean"]).all()
+
+
+def test_transient_integrator_shares_the_nan_rule():
+    """render.py:307-311 repeats the statement of :233-237; the transient witness must carry the same binding."""
+    import inspect
+
+    from oracle import transient_ref
+    src = inspect.getsource(transient_ref.transient_integrate)
+    assert "nan=0.0" in src and 'nan=float("inf")' not in src
+
+
+def test_safe_exp_propagates_nan_like_jnp_clip():
+    """math.safe_exp = exp(jnp.clip(x, min, 70)); jnp.clip = minimum(maximum(.)) propagates a NaN (JAX_CALLS.md N3)."""
+    from oracle import spec_np
+    x = torch.tensor([float("nan"), 80.0, -float("inf")])
+    y = mathx.safe_exp(x)
+    assert torch.isnan(y[0]) and float(y[1]) == pytest.approx(math.exp(70.0), rel=1e-6) and float(y[2]) == 0.0
+    assert np.isnan(spec_np.exp_safe(np.array([np.nan]))[0])
