@@ -88,33 +88,45 @@ def host_cpu_share(cap=16):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(cfg, weights_np, n_rays, budget_s=20.0):
-    """Oracle (torch fp32 on the host cores this process may use) on the same 1024-ray batch.  Bounded: every pass
-    is timed (the first one too), passes stop once `budget_s` is spent; progress goes to stderr."""
+def cpu_baseline(cfg, weights_np, n_rays, warmup=3, timed=10, budget_s=90.0):
+    """BASELINE.md §2 / SURVEY §8(d) protocol: the torch-fp32 oracle on the same 1024-ray batch at N = 8 threads AND at
+    N = all host cores this process is granted, 3 warm-up + 10 timed passes each, MEDIAN reported; `value` / `cores` are
+    the all-cores run, `runs` holds both.  Bounded: a thread count stops early (and says so) once `budget_s` is spent in
+    total; progress goes to stderr."""
     import numpy as np
     import torch
 
     import nrc_amd
     from oracle import cache_ref
 
-    cores = host_cpu_share()
-    torch.set_num_threads(cores)
+    granted = host_cpu_share()
     wt = {k: torch.from_numpy(v) for k, v in weights_np.items()}
     rays = nrc_amd.synthetic_rays(n_rays)
     rt = {k: torch.from_numpy(np.asarray(v)) for k, v in rays.hot_fields().items()}
     run = lambda: cache_ref.cache_forward(wt, cfg, rt, None, want_grad_normals=True, exec_dead_envmap=True)
-    times = []
+    runs = []
     t_start = time.time()
-    while len(times) < 8 and (time.time() - t_start < budget_s or len(times) < 1):
-        t0 = time.time()
-        run()
-        times.append(time.time() - t0)
-        print(f"[bench] cpu_baseline pass {len(times)}: {times[-1]:.2f} s on {cores} threads", file=sys.stderr, flush=True)
-    timed = times[1:] if len(times) > 1 else times          # the first pass warms the allocator / thread pool up
-    med = sorted(timed)[len(timed) // 2]
-    return {"value": n_rays / med, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(timed)} timed passes of one {n_rays}-ray batch (64,64,32 samples), torch fp32 oracle "
-                      f"incl. the reference's dead cache-EnvMap MLP and autograd normals; median {med*1e3:.0f} ms"}
+    for cores in sorted({min(8, granted), granted}):
+        torch.set_num_threads(cores)
+        times = []
+        for i in range(warmup + timed):
+            if i > warmup and time.time() - t_start > budget_s:
+                break
+            t0 = time.time()
+            run()
+            dt = time.time() - t0
+            if i >= warmup:
+                times.append(dt)
+            print(f"[bench] cpu_baseline {cores} threads, pass {i + 1}/{warmup + timed}"
+                  f"{' (warm-up)' if i < warmup else ''}: {dt:.2f} s", file=sys.stderr, flush=True)
+        med = sorted(times)[len(times) // 2]
+        runs.append({"cores": torch.get_num_threads(), "value": n_rays / med, "unit": "rays/s", "median_ms": med * 1e3,
+                     "warmup": warmup, "timed": len(times)})
+    best = runs[-1]                                       # all granted cores
+    return {"value": best["value"], "unit": "rays/s", "cores": best["cores"], "kind": "port", "runs": runs,
+            "sample": f"{warmup} warm-up + {best['timed']} timed passes of one {n_rays}-ray batch (64,64,32 samples) per thread "
+                      f"count (8 and all {granted} granted host cores), torch fp32 oracle incl. the reference's dead "
+                      f"cache-EnvMap MLP and autograd normals; median {best['median_ms']:.0f} ms at {best['cores']} threads"}
 
 
 def transient_line(local_rank, dev, n_rays=1024, steps=20, warmup=3):
@@ -271,9 +283,30 @@ def image_line(rc_model, cfg, dev, world, rank, dist, reps=3):
         if i:
             times.append(dt)
     ms = sorted(times)[len(times) // 2] * 1e3
+    # the same image handed over the way render_image hands it over (numpy on the host, internal/models.py:2448-2450 copies
+    # every chunk; here ONE device-to-host copy of the gathered keys per image): end-to-end wall clock incl. that copy
+    host_times = []
+    for i in range(reps + 1):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        himg = M.render_image_distributed(apply, None, rays, icfg, keys=keys, to_host=True)
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if i:
+            host_times.append(dt)
+    assert isinstance(himg["rgb"], np.ndarray) and himg["rgb"].shape == (H, W, 3)
+    ms_host = sorted(host_times)[len(host_times) // 2] * 1e3
     return {"workload": "lego/hotdog-architecture 800x800 image, rays sharded over the ranks, one all-gather of "
                         "rgb+acc+distance_median+normals_pred per image (configs[3])",
             "scaling": "strong", "n_gpus": world, "ms_per_image": ms, "rays_per_s": H * W / (ms * 1e-3),
+            "ms_per_image_to_host": ms_host, "rays_per_s_to_host": H * W / (ms_host * 1e-3),
+            "to_host_note": "ms_per_image ends device-complete (results in HBM); ms_per_image_to_host adds the single "
+                            "device-to-host copy of the gathered keys (20.5 MB) into numpy arrays",
             "render_chunk_size": icfg.render_chunk_size, "acc_mean": float(img["acc"].mean()),
             "collective": "all_gather_into_tensor over RCCL" if world > 1 else "none (one rank)"}
 

@@ -819,9 +819,27 @@ def _advance_rng(rng, rank: int, first: bool):
     return rng, rng
 
 
+_PINNED: Dict[Tuple[int, ...], Any] = {}
+
+
+def _to_host_once(t):
+    """One device-to-host copy of a [rays, columns] float32 tensor into a (cached) pinned buffer; returns numpy."""
+    import torch
+    if not t.is_cuda:
+        return t.numpy()
+    shape = tuple(t.shape)
+    host = _PINNED.get(shape)
+    if host is None:
+        _PINNED.clear()                                   # one image size at a time: do not hoard pinned memory
+        host = _PINNED[shape] = torch.empty(shape, dtype=torch.float32, pin_memory=True)
+    host.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return host.numpy().copy()                            # the caller owns its arrays; the staging buffer is reused
+
+
 def render_image_distributed(model_apply, rng, rays: Rays, config, passes=("cache",), keys=GATHER_KEYS,
                              group=None, device=None, key_widths: Optional[Dict[str, int]] = None,
-                             num_repeats: int = 1):
+                             num_repeats: int = 1, to_host: bool = False):
     """Each rank renders its contiguous share of the image in `render_chunk_size` batches, keeps the
     results on its device, packs the consumed keys into one [rays_per_rank, sum(widths)] buffer and
     issues ONE all_gather per image (the reference all-gathers the whole ~45-key dict per chunk per
@@ -832,7 +850,9 @@ def render_image_distributed(model_apply, rng, rays: Rays, config, passes=("cach
 
     model_apply(rng, rays) -> {"render": {key: tensor[n, ...]}}; runs on "nccl" (= RCCL over xGMI)
     with the HIP model and on "gloo" with any CPU callable (tests).  `device`: where a rank with an empty shard
-    allocates its (all-padding) contribution; defaults to the current cuda device under the nccl backend."""
+    allocates its (all-padding) contribution; defaults to the current cuda device under the nccl backend.
+    `to_host=True` returns float32 numpy arrays, as `render_image` does (internal/models.py:2448-2450 copies every chunk of
+    every key; here the gathered keys cross PCIe as ONE device-to-host copy per image, into a pinned staging buffer)."""
     import torch
     import torch.distributed as dist
 
@@ -888,6 +908,8 @@ def render_image_distributed(model_apply, rng, rays: Rays, config, passes=("cach
             dist.all_gather(list(gathered.chunk(world, dim=0)), buf, group=group)
     else:
         gathered = buf
+    if to_host:
+        gathered = _to_host_once(gathered[:num_rays])
     result = {}
     for i, k in enumerate(keys):
         v = gathered[:num_rays, cols[i]: cols[i + 1]]

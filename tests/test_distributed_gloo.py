@@ -79,6 +79,12 @@ def test_two_rank_sharded_render_equals_single_process():
     assert got["rgb"].shape == (H, W, 3) and got["acc"].shape == (H, W)
     for k in got:
         assert np.allclose(got[k], single[k].numpy(), atol=1e-6), k   # same arithmetic per ray (batch shapes differ)
+    # to_host=True: what render_image returns (numpy on the host), same values, caller-owned arrays
+    host = M.render_image_distributed(_oracle_apply(cfg, common.weights_torch()), None, rays, _Cfg(),
+                                      keys=("rgb", "acc", "distance_median"), to_host=True)
+    for k in single:
+        assert isinstance(host[k], np.ndarray) and host[k].dtype == np.float32
+        assert np.array_equal(host[k], single[k].numpy()), k
 
 
 # ---- num_repeats > 1: the running mean covers the reference's stat_keys only (internal/models.py:2398-2401, 2473-2490)

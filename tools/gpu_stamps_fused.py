@@ -82,4 +82,11 @@ if len(sys.argv) > 3:      # JSON for profiles/fused_phase_stamps.json (bench.py
                "how": "tools/gpu_stamps_fused.py on the -DRC_STAMPS build (make diag): s_memtime at the phase boundaries of "
                       "k_cache_fused, median over the rays of one 1024-ray batch; the stamps add ~3 % to the kernel"},
               open(sys.argv[3], "w"), indent=1)
-print("gather0 detail us: pos+contract", np.median(d[:, 12] - d[:, 1]) / ghz / 1e3, "issue", np.median(d[:, 13] - d[:, 12]) / ghz / 1e3, "wait+combine", np.median(d[:, 2] - d[:, 13]) / ghz / 1e3)
+# Slots 12 / 13 hold detail stamps INSIDE the first lookup only in the one-wave kernel (rc_fused.hip); the two-wave kernel
+# (rc_fused2.hip, the default) keeps its hand-off barrier wait / count + HW_ID there (RC_STAMP_DETAIL above).  Print the
+# detail line only when the slots really are time stamps between phase 1 and phase 2 of (nearly) every ray.
+is_detail = np.mean((d[:, 1] <= d[:, 12]) & (d[:, 12] <= d[:, 13]) & (d[:, 13] <= d[:, 2])) > 0.95
+if is_detail:
+    print("gather0 detail us: pos+contract", np.median(d[:, 12] - d[:, 1]) / ghz / 1e3, "issue", np.median(d[:, 13] - d[:, 12]) / ghz / 1e3, "wait+combine", np.median(d[:, 2] - d[:, 13]) / ghz / 1e3)
+else:
+    print("gather0 detail: not stamped by this kernel (two-wave kernel: slots 12 / 13 = hand-off wait, count | HW_ID)")
