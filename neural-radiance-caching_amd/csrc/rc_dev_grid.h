@@ -120,16 +120,41 @@ __device__ __forceinline__ void grid_fetch_cell(const float* __restrict__ cell_t
 // `dense` may differ between the two half-waves of a wave (the level kernels split a point's levels by parity): the two
 // sides then run one after the other under exec masks and only compute the eight entry INDICES; the eight loads are
 // common code behind them -- loads inside the sides target the same registers and would wait for each other.
-template <int F, bool POW2 = false, int STRIDE = 1, bool CELL = false>
+// UNIFORM: the caller guarantees a wave-uniform `dense` (the stand-alone lookup kernels: the level is blockIdx.y): each side
+// then computes a corner's index and issues its load at once, pair by pair (the form of rounds 1-2), instead of eight
+// indices first and the eight loads as one burst behind the merge.  Same registers, same instruction counts -- and 22.2
+// against 26.2 us for k_hashgrid_fwd<4, JAC> on the bench's 32 768 points (19.3 / 23.0 without the Jacobian): eight 16-byte
+// wave-loads back to back from every wave queue up in front of the texture-address unit; spaced by their index arithmetic
+// they interleave with the other waves' (profiles/r04_bisect_hashgrid_standalone.txt: `abold` = this header's
+// predecessor under HEAD's library).
+template <int F, bool POW2 = false, int STRIDE = 1, bool CELL = false, bool UNIFORM = false>
 __device__ __forceinline__ void grid_fetch(const float* __restrict__ table, int size, uint32_t mask, uint32_t entries,
                                            bool dense, float x01, float y01, float z01, Corners<F>& C) {
   C.zero_mask = 0;
   uint32_t idx[8];
+  // fetch order: the two corners that differ in b0 -- x and x + 1: adjacent entries of a dense level, an index that
+  // differs in the low bits only on a hashed one (same cache line 7 times out of 8) -- back to back
+  auto visit = [&](auto&& index_of) {
+    if constexpr (UNIFORM) {
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        const int c = ((o & 1) << 2) | (o >> 1);
+        uint32_t i = index_of(c) * STRIDE;
+        // An empty volatile asm on the index of every x-pair pins the pair behind its own index arithmetic: the optimizer
+        // otherwise sinks the (identical) loads of the two sides into the block behind them and the scheduler clusters
+        // them -- the burst again (inline asm is neither sunk nor crossed by memory operations; it emits nothing).
+        if ((o & 1) == 0) asm volatile("" : "+v"(i));
+        C.val[c] = load_entry<F>(table, i);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) idx[c] = index_of(c);
+    }
+  };
   if (dense) {
     if constexpr (CELL) {
       const uint32_t cell = cell_index(size, x01, y01, z01, C.cw);
-#pragma unroll
-      for (int c = 0; c < 8; ++c) idx[c] = cell * 8u + (uint32_t)c;
+      visit([&](int c) { return cell * 8u + (uint32_t)c; });
     } else {
       const float N = (float)size;
       const float cx = x01 * N, cy = y01 * N, cz = z01 * N;     // x01 * grid_size (grid_utils.py:820, 863)
@@ -155,13 +180,12 @@ __device__ __forceinline__ void grid_fetch(const float* __restrict__ table, int 
           const uint32_t km = (uint32_t)(k - 1);
           term[a][b] = a == 0 ? km : (a == 1 ? km * (uint32_t)size : km * (uint32_t)size * (uint32_t)size);
         }
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
+      visit([&](int c) {
         const int b0 = (c >> 2) & 1, b1 = (c >> 1) & 1, b2 = c & 1;
         const bool zero = out[0][b0] | out[1][b1] | out[2][b2];
-        idx[c] = zero ? 0u : term[2][b2] + term[1][b1] + term[0][b0];
         C.zero_mask |= (zero ? 1u : 0u) << c;
-      }
+        return zero ? 0u : term[2][b2] + term[1][b1] + term[0][b0];
+      });
     }
   } else {
     const float N = (float)size;
@@ -178,19 +202,18 @@ __device__ __forceinline__ void grid_fetch(const float* __restrict__ table, int 
     const uint32_t hx[2] = {(uint32_t)base[0], (uint32_t)base[0] + 1u};
     const uint32_t y0 = (uint32_t)base[1] * kPi2, z0 = (uint32_t)base[2] * kPi3;
     const uint32_t hy[2] = {y0, y0 + kPi2}, hz[2] = {z0, z0 + kPi3};
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    visit([&](int c) {
       const int b0 = (c >> 2) & 1, b1 = (c >> 1) & 1, b2 = c & 1;
       const uint32_t hsh = hx[b0] ^ hy[b1] ^ hz[b2];
-      idx[c] = (POW2 || mask) ? (hsh & mask) : (hsh % entries);
-    }
+      return (POW2 || mask) ? (hsh & mask) : (hsh % entries);
+    });
   }
-  // fetch order: the two corners that differ in b0 -- x and x + 1: adjacent entries of a dense level, an index that
-  // differs in the low bits only on a hashed one (same cache line 7 times out of 8) -- back to back
+  if constexpr (!UNIFORM) {
 #pragma unroll
-  for (int o = 0; o < 8; ++o) {
-    const int c = ((o & 1) << 2) | (o >> 1);
-    C.val[c] = load_entry<F>(table, idx[c] * STRIDE);
+    for (int o = 0; o < 8; ++o) {
+      const int c = ((o & 1) << 2) | (o >> 1);
+      C.val[c] = load_entry<F>(table, idx[c] * STRIDE);
+    }
   }
 }
 
@@ -276,7 +299,12 @@ __device__ __forceinline__ void pair_finish(const PairCorners& P, Corners<1>& C)
   }
 }
 
-template <int F, bool JAC>
+// PACKED (F = 4): the four features as two register pairs on v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 -- the same separate
+// roundings per element, bitwise the same result.  The fused and level kernels use it (-6 % static vector instructions
+// next to their MFMA work); the stand-alone lookup kernels do not: the register pairs it needs take k_hashgrid_fwd<4, JAC>
+// from 62 to 76 vector registers -- six instead of eight waves per SIMD on a kernel that lives on its loads in flight
+// (profiles/r04_bisect_hashgrid_standalone.txt: +2 us per launch at commit 241cc23 against 1a919e3).
+template <int F, bool JAC, bool PACKED = true>
 __device__ __forceinline__ void grid_combine(const Corners<F>& C, float (&acc)[F], float (&jacc)[JAC ? 3 * F : 1]) {
   float fw[3];
 #pragma unroll
@@ -284,7 +312,7 @@ __device__ __forceinline__ void grid_combine(const Corners<F>& C, float (&acc)[F
 #pragma unroll
   for (int f = 0; f < F; ++f) acc[f] = 0.0f;
   float v[8][F];
-  if constexpr (F == 4) {
+  if constexpr (F == 4 && PACKED) {
     // the four features as two register pairs: packed multiplies and adds (v_pk_mul_f32 / v_pk_add_f32, two lanes of
     // fp32 per instruction, the same separate roundings per element)
     f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
@@ -325,7 +353,7 @@ __device__ __forceinline__ void grid_combine(const Corners<F>& C, float (&acc)[F
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int k = 0; k < 2; ++k) { p12[i][k] = w1s[i] * w2s[k]; p02[i][k] = w0s[i] * w2s[k]; p01[i][k] = w0s[i] * w1s[k]; }
-    if constexpr (F == 4) {
+    if constexpr (F == 4 && PACKED) {
       // packed over feature pairs as above (v_pk_add_f32 with a negated operand, v_pk_fma_f32)
 #pragma unroll
       for (int fp = 0; fp < 2; ++fp) {
@@ -375,8 +403,12 @@ __device__ __forceinline__ void grid_level(const RcGridLevel& L, float bbox, flo
       return;
     }
   }
-  grid_fetch<F>(L.table, L.size, L.mask, L.entries, L.dense != 0, unit_box(bbox, x), unit_box(bbox, y), unit_box(bbox, z), C);
-  grid_combine<F, JAC>(C, acc, jacc);
+  // power-of-two table or not decided ONCE per level (wave-uniform): as a test per corner the modulo path put eight
+  // branches and ~160 instructions between the index arithmetic and the first load (r04_bisect_hashgrid_standalone.txt)
+  const float x01 = unit_box(bbox, x), y01 = unit_box(bbox, y), z01 = unit_box(bbox, z);
+  if (L.dense != 0 || L.mask != 0u) grid_fetch<F, true, 1, false, true>(L.table, L.size, L.mask, L.entries, L.dense != 0, x01, y01, z01, C);
+  else grid_fetch<F, false, 1, false, true>(L.table, L.size, L.mask, L.entries, false, x01, y01, z01, C);
+  grid_combine<F, JAC, false>(C, acc, jacc);
 }
 
 }  // namespace rcdev
