@@ -357,7 +357,17 @@ int build_fused_tables(rc_handle* h) {
     for (int g = 0; g < 3; ++g)
       for (int l = 0; l < h->grids[g].dev.num_levels; ++l) {
         const RcGridLevel& L = h->grids[g].dev.lvl[l];
-        if (!L.dense) continue;
+        if (!L.dense) {
+          // the first hashed levels of the F = 1 grids as cell records (kLevelHRec): (N + 1)^3 records of 8 floats
+          if (g < 2 && l < kRcFusedDenseLevels + kRcRecLevels && L.mask != 0) {
+            const size_t nrec = (size_t)(L.size + 1) * (L.size + 1) * (L.size + 1);
+            float* dst = nullptr;
+            if ((rc = cells("rec" + std::to_string(g) + "_" + std::to_string(l), nrec * 8, &dst))) return rc;
+            rc_launch_build_hrec(L.table, L.size, L.mask, dst, nullptr);
+            h->grids[g].dev.lvl[l].rec = dst;
+          }
+          continue;
+        }
         const size_t ncell = (size_t)(L.size + 3) * (L.size + 3) * (L.size + 3);
         float* dst = nullptr;
         if (g < 2) {
@@ -384,7 +394,8 @@ void build_fused_template(rc_handle* h) {
   for (int l = 0; l < h->grids[2].dev.num_levels; ++l) F.pair_table[l] = h->packs["pair_" + std::to_string(l)].p;
   for (int g = 0; g < 2; ++g)
     for (int l = 0; l < h->grids[g].dev.num_levels; ++l)
-      F.cell_table[g][l] = h->grids[g].dev.lvl[l].dense ? h->packs["cell" + std::to_string(g) + "_" + std::to_string(l)].p : nullptr;
+      F.cell_table[g][l] = h->grids[g].dev.lvl[l].dense ? h->packs["cell" + std::to_string(g) + "_" + std::to_string(l)].p
+                                                        : h->grids[g].dev.lvl[l].rec;      // cell records of a kLevelHRec level, or NULL
   F.wstream = h->packs["fused"].p; F.ide_coef = h->ide_table.p;
   F.anneal = c.anneal; F.padding = c.resample_padding; F.density_bias = c.density_bias;
   F.contract_radius = c.contract_radius; F.bg = c.bg_intensity;
@@ -863,6 +874,7 @@ int rc_load_weights(rc_handle* h, const rc_tensor_desc* descs, int32_t n) {
         RC_HIP(h, hipMemcpy(b.p, d.data, bytes, d.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
         gs.dev.lvl[l].table = b.p;
         gs.dev.lvl[l].cell = nullptr;    // the derived cell table is stale until the next repack
+        gs.dev.lvl[l].rec = nullptr;
         gs.loaded[l] = true;
         h->packed_dirty = true;          // derived device copies (interleaved level-2 tables) follow the tables
         handled = true;
@@ -1075,7 +1087,8 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     for (int l = 0; l < h->grids[2].dev.num_levels; ++l) F.pair_table[l] = h->packs["pair_" + std::to_string(l)].p;
     for (int g = 0; g < 2; ++g)
       for (int l = 0; l < h->grids[g].dev.num_levels; ++l)
-        F.cell_table[g][l] = h->grids[g].dev.lvl[l].dense ? h->packs["cell" + std::to_string(g) + "_" + std::to_string(l)].p : nullptr;
+        F.cell_table[g][l] = h->grids[g].dev.lvl[l].dense ? h->packs["cell" + std::to_string(g) + "_" + std::to_string(l)].p
+                                                        : h->grids[g].dev.lvl[l].rec;      // cell records of a kLevelHRec level, or NULL
     F.wstream = h->packs["fused_front"].p; F.ide_coef = nullptr;
     F.anneal = c.anneal; F.padding = c.resample_padding; F.density_bias = c.density_bias;
     F.contract_radius = c.contract_radius; F.bg = c.bg_intensity;

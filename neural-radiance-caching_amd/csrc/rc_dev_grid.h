@@ -229,7 +229,30 @@ __device__ __forceinline__ void grid_fetch(const float* __restrict__ table, int 
 // a random gather (profiles/r03_two_wave_probe.txt), and no divergence, the kinds being compile-time.  When the values
 // have arrived, four v_permlane32_swap hand each half-wave the other four corners of ITS level; grid_combine then adds
 // them in the reference's corner order as before (bitwise the same feature).
-enum : int { kLevelNone = -1, kLevelHashed = 0, kLevelCell = 2 };    // kinds of a level (hashed: power-of-two table)
+enum : int { kLevelNone = -1, kLevelHashed = 0, kLevelCell = 2, kLevelHRec = 3 };    // kinds of a level (hashed: power-of-two table)
+
+// kind of level l of an F = 1 grid in the reference's layout (nd leading dense levels, each with its cell table; the
+// next kRcRecLevels hashed levels through their cell records)
+constexpr int ref_level_kind(int l, int nd) { return l < nd ? kLevelCell : (l < nd + kRcRecLevels ? kLevelHRec : kLevelHashed); }
+
+// Record of a hashed level in its cell-record table and the three interpolation weights: the hashed branch's location
+// x01 * N - 0.5 in (x, y, z) order (grid_utils.py:61), cell origin floor(.) in [-1, N - 1] for every point inside the
+// bounding box (x01 in [0, 1]); outside it the origin is clamped -- the record is then not the point's cell, and every
+// consumer of an F = 1 grid zeroes the density of such a point (convert_raw_density, geometry.py:333-337) whatever its
+// features are.  Weights and corner order are the hashed lookup's own: bitwise the same feature inside the box.
+__device__ __forceinline__ uint32_t hrec_index(int size, float x01, float y01, float z01, float (&cw)[3]) {
+  const float N = (float)size;
+  const float loc[3] = {x01 * N - 0.5f, y01 * N - 0.5f, z01 * N - 0.5f};
+  int q[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float fl = floorf(loc[a]);
+    cw[a] = loc[a] - fl;
+    q[a] = min(max((int)fl, -1), size - 1) + 1;
+  }
+  const uint32_t M = (uint32_t)size + 1u;
+  return __umul24(__umul24((uint32_t)q[0], M) + (uint32_t)q[1], M) + (uint32_t)q[2];
+}
 
 struct PairCorners { float va[4], vb[4]; float cw[3]; };
 
@@ -237,8 +260,8 @@ struct PairCorners { float va[4], vb[4]; float cw[3]; };
 template <int KIND>
 __device__ __forceinline__ void half_corners(const float* __restrict__ table, int size, uint32_t mask, int h, float x01,
                                              float y01, float z01, float (&cw)[3], float (&v)[4]) {
-  if constexpr (KIND == kLevelCell) {
-    const uint32_t cell = cell_index(size, x01, y01, z01, cw);
+  if constexpr (KIND == kLevelCell || KIND == kLevelHRec) {
+    const uint32_t cell = KIND == kLevelCell ? cell_index(size, x01, y01, z01, cw) : hrec_index(size, x01, y01, z01, cw);
     const f32x4 q = *reinterpret_cast<const f32x4*>(table + (size_t)cell * 8 + 4 * h);
     v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
   } else {

@@ -182,11 +182,12 @@ __device__ __forceinline__ float level_tile(const RcFusedArgs& a, const WStream&
   PairCorners P[NH];
   static_for<NH>([&](auto I) {
     constexpr int i = decltype(I)::value, la = 2 * i, lb = 2 * i + 1;
-    constexpr int ka = la < kFusedDense ? kLevelCell : kLevelHashed;
-    constexpr int kb = lb >= NL ? kLevelNone : (lb < kFusedDense ? kLevelCell : kLevelHashed);
+    constexpr int ka = ref_level_kind(la, kFusedDense);
+    constexpr int kb = lb >= NL ? kLevelNone : ref_level_kind(lb, kFusedDense);
     const RcGridLevel &LA = grid.lvl[la], &LB = grid.lvl[lb < NL ? lb : la];
-    pair_fetch<ka, kb>(ka == kLevelCell ? a.cell_table[G][la] : LA.table, LA.size, LA.mask,
-                       kb == kLevelCell ? a.cell_table[G][lb < NL ? lb : la] : LB.table, LB.size, LB.mask, hh, ux, uy, uz, P[i]);
+    // a.cell_table: the cell table of a dense level, the cell records of a kLevelHRec one
+    pair_fetch<ka, kb>(ka != kLevelHashed ? a.cell_table[G][la] : LA.table, LA.size, LA.mask,
+                       (kb == kLevelCell || kb == kLevelHRec) ? a.cell_table[G][lb < NL ? lb : la] : LB.table, LB.size, LB.mask, hh, ux, uy, uz, P[i]);
   });
   __builtin_amdgcn_sched_barrier(0);
   // feature l of point j -> step l / 2, half l & 1 = hh: this lane's own column

@@ -41,6 +41,8 @@ struct RcGridLevel {
   uint32_t mask;        // T-1 if T is a power of two, else 0
   const float* cell;    // dense F = 1 levels of the proposal grids: cell table ((N+3)^3 cells x 8 corners, zero padding
                         // baked in; built with the fused kernel's tables) or nullptr
+  const float* rec;     // hashed F = 1 levels [kRcFusedDenseLevels, + kRcRecLevels) of the proposal grids: cell records
+                        // ((N+1)^3 cell origins x the 8 hashed corner values, rc_launch_build_hrec) or nullptr
 };
 
 struct RcGridDev {
@@ -299,6 +301,20 @@ struct RcFusedLaunch {
 // the fused kernels are compiled for this level layout of every grid: levels [0, kRcFusedDenseLevels) dense (16, 32, 64
 // cells a side against 2^19 entries), the others hashed
 constexpr int kRcFusedDenseLevels = 3;
+// ... and the first kRcRecLevels hashed levels of the F = 1 grids are read through cell RECORDS: one 32-byte record per
+// cell origin with the 8 hashed corner values side by side, so a lookup is ONE sector instead of four (rc_dev_grid.h
+// kLevelHRec).  69 MB per grid for the 128^3 level, 543 MB for 256^3, 4.3 GB for 512^3.  Measured (same box, builds with
+// 0 | 1 | 2 record levels, profiles/r04_ab_cell_records.txt): fused kernel 124.8 | 124.3 | 123.5 us per 1024 rays, 1720 |
+// 1707 | 1716 us per 16 384, material stage 1.437 | 1.414 | 1.422 ms -- one level is worth 0.5-1.7 %, the second nothing:
+// four x-pair sectors out of a 2 MiB table (L2) cost what one sector out of a table behind the L2 costs
+// (profiles/r04_gather_cell_records.txt: 65 G lookups/s against 54-59).  One level it is.
+#ifndef RC_REC_LEVELS
+#define RC_REC_LEVELS 1
+#endif
+constexpr int kRcRecLevels = RC_REC_LEVELS;
+// dst[(N+1)^3][8]: record (qx, qy, qz) in [0, N]^3 = cell origin (qx - 1, qy - 1, qz - 1), corner c = 4 b0 + 2 b1 + b2 at
+// origin + (b0, b1, b2) through the level's hash (power-of-two table)
+void rc_launch_build_hrec(const float* table, int N, uint32_t mask, float* dst, hipStream_t stream);
 int rc_fused_stream_offsets(int* l0, int* l1, int* l2, int* sh);   // returns the total fragment count
 void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream);
 // dst[cell][corner][dst_stride floats, written F at dst_off]: the 8 corners of every cell of the zero-padded dense

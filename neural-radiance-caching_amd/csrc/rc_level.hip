@@ -105,11 +105,11 @@ struct LevelK {
       PairCorners P[NH];
       static_for<NH>([&](auto I) {
         constexpr int i = decltype(I)::value, la = 2 * i, lb = 2 * i + 1 < NL ? 2 * i + 1 : 2 * i;
-        constexpr int ka = la < ND ? kLevelCell : kLevelHashed;
-        constexpr int kb = 2 * i + 1 >= NL ? kLevelNone : (lb < ND ? kLevelCell : kLevelHashed);
+        constexpr int ka = ref_level_kind(la, ND);
+        constexpr int kb = 2 * i + 1 >= NL ? kLevelNone : ref_level_kind(lb, ND);
         const RcGridLevel &LA = grid.lvl[la], &LB = grid.lvl[lb];
-        pair_fetch<ka, kb>(ka == kLevelCell ? LA.cell : LA.table, LA.size, LA.mask, kb == kLevelCell ? LB.cell : LB.table,
-                           LB.size, LB.mask, h, ux, uy, uz, P[i]);
+        pair_fetch<ka, kb>(ka == kLevelCell ? LA.cell : (ka == kLevelHRec ? LA.rec : LA.table), LA.size, LA.mask,
+                           kb == kLevelCell ? LB.cell : (kb == kLevelHRec ? LB.rec : LB.table), LB.size, LB.mask, h, ux, uy, uz, P[i]);
       });
       __builtin_amdgcn_sched_barrier(0);
       // feature l of point j -> step l / 2, half l & 1 = h: this lane's own column
@@ -342,6 +342,7 @@ int level_layout(const RcGridDev& g) {
   for (int l = 0; l < g.num_levels; ++l) {
     const bool want_dense = l < kRefDense;
     if ((g.lvl[l].dense != 0) != want_dense || (want_dense && !g.lvl[l].cell)) return -1;
+    if (!want_dense && l < kRefDense + kRcRecLevels && !g.lvl[l].rec) return -1;      // compiled for cell records there
   }
   return kRefDense;
 }
