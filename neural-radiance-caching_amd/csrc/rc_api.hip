@@ -130,6 +130,10 @@ struct rc_handle {
   // EnvMap along the secondary rays) runs on this stream, forked from / joined to the caller's with events
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_side[4] = {nullptr, nullptr, nullptr, nullptr};
+  // rc_density_backward: weight gradients ([0]) and the LDS-accumulated table levels ([1]) beside the scatter of the other
+  // levels on the caller's stream (highest priority; events: fork, join [0], join [1])
+  hipStream_t train_stream[2] = {nullptr, nullptr};
+  hipEvent_t ev_train[3] = {nullptr, nullptr, nullptr};
   std::vector<GraphEntry> graphs;
   RenderKey last_key{};
   bool have_last_key = false;
@@ -403,6 +407,17 @@ void build_fused_template(rc_handle* h) {
   F.roughness_bias = c.roughness_bias; F.irradiance_bias = c.irradiance_bias; F.ambient_bias = c.ambient_irradiance_bias;
   F.rgb_max = c.rgb_max; F.slf_ambient_bias = c.slf_ambient_bias;
   h->fused_tmpl = F;
+}
+
+// The handle's side stream (work that only feeds a call's outputs, forked from / joined to the caller's stream with events)
+// at the lowest priority: the kernels on the caller's stream -- the critical path -- get the CUs first.
+int ensure_side_stream(rc_handle* h) {
+  if (h->side_stream) return RC_OK;
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  RC_HIP(h, hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio_lo));
+  for (hipEvent_t& e : h->ev_side) RC_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return RC_OK;
 }
 
 int repack_transient(rc_handle* h);
@@ -833,6 +848,8 @@ void rc_destroy(rc_handle* h) {
   for (auto& G : h->groups) if (G.done) (void)hipEventDestroy(G.done);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+  for (hipStream_t s : h->train_stream) if (s) (void)hipStreamDestroy(s);
+  for (hipEvent_t e : h->ev_train) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_side) if (e) (void)hipEventDestroy(e);
   if (h->ev_created)
     for (int s = 0; s < kEvSlots; ++s)
@@ -1569,14 +1586,7 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
   // feed only the outputs / the final integration, so they leave the critical path sampler -> trace -> integrate and
   // fill the gaps of its latency-bound kernels.  Forked from and joined to the caller's stream with events: to the
   // caller the call is still ordered on `st` alone.
-  if (!h->side_stream) {
-    // lowest priority: what runs here (light sampler, material-only pass, EnvMap) only feeds the outputs and the step's
-    // last kernel; the kernels on the caller's stream -- the critical path -- get the CUs first
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    RC_HIP(h, hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio_lo));
-    for (hipEvent_t& e : h->ev_side) RC_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
+  { int rcs = ensure_side_stream(h); if (rcs) return rcs; }
   hipStream_t side = h->side_stream;
   // Whatever way this function is left once work has been forked onto the side stream, the caller's stream is joined
   // to it again BEFORE the workspace set is released (declared after LeaveGuard: destroyed first): an early error

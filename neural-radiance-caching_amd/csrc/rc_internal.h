@@ -428,7 +428,10 @@ struct RcGridScatterArgs {
   int32_t level0;             // first level of this launch (blockIdx.y = level - level0)
   uint32_t lds_levels;        // bit l: level l is summed through LDS by k_grid_scatter_small
 };
-void rc_launch_grid_scatter(const RcGridScatterArgs& a, hipStream_t stream);
+// small_stream (optional): where the LDS-accumulated levels (k_grid_scatter_small) go; they are independent of the
+// other levels' scatter and of each other (disjoint tables) -- the caller orders both streams
+void rc_launch_grid_scatter(const RcGridScatterArgs& a, hipStream_t stream, hipStream_t small_stream = nullptr, bool use_small_stream = false);
+bool rc_train_prepare();     // LDS opt-in of the scatter kernels (call once outside any stream capture)
 
 // Random fill (rc_prng.hip)
 enum { RC_PRNG_BITS = 0, RC_PRNG_UNIFORM = 1, RC_PRNG_NORMAL = 2, RC_PRNG_GUMBEL = 3 };

@@ -377,9 +377,100 @@ __global__ __launch_bounds__(256) void k_grid_scatter_small(RcGridScatterArgs a,
   }
   __syncthreads();
   float* __restrict__ gt = a.gtable[l];
-  for (int i = threadIdx.x; i < total; i += 256) {
+  // Flush by whole 64-byte rows: a row (16 lanes) is added if any of its entries is non-zero, all 16 lanes then take part --
+  // the memory side works on 64-byte rows, and an instruction of complete rows runs at the contiguous rate where single
+  // entries of a row picked by `v != 0` run at the scattered one (the 32^3 level: 49 -> 20 us).
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < total; i += 256) {      // total is a multiple of 256 for every table that fits (16^3, 32^3)
     const float v = tab[i];
-    if (v != 0.0f) unsafeAtomicAdd(gt + i, v);
+    const unsigned long long nz = __ballot(v != 0.0f);
+    if ((nz >> (lane & 48)) & 0xFFFFull) unsafeAtomicAdd(gt + i, v);
+  }
+}
+
+
+// Levels with many adds per 64-byte row, ONE launch, no scattered atomics: a level's gradient table is cut into slices of
+// 32 768 floats (128 KiB of LDS; F = 1: 16^3 and 32^3 are one slice, 64^3 eight, a 2^19-entry hash table sixteen; F = 4:
+// 16^3 one, 32^3 four, 64^3 thirty-two) and the points into `parts` ranges; workgroup (level, slice, part) walks its range,
+// computes the eight corner indices of every point and sums the corners that fall into ITS slice in LDS (ds_add_f32),
+// then adds the slice to HBM as whole 64-byte rows.  Why: the memory side executes float atomics per request -- 18.5 G
+// requests/s whatever they carry (k_grid_scatter<4>: 16-byte entries, k_grid_scatter<1>: 4-byte lanes, the x-pair lanes
+// are not merged) -- and a batch of 65 536 samples puts sixteen adds into every row of a hashed F = 1 table (32 768
+// samples: four to thirty-two into every row of the dense F = 4 levels): summed on chip first, a row costs `parts`
+// full-row requests instead.  The index arithmetic is redone once per slice: ~80 instructions per point and slice against
+// a memory-side request.  (Hashed F = 4 levels: two adds per row -- nothing to merge, they stay with k_grid_scatter<4>.)
+struct RcSlicedPlan {
+  int32_t wg_base[RC_MAX_GRID_LEVELS + 1];     // workgroups [wg_base[l], wg_base[l + 1]) belong to level l
+  int32_t nslice[RC_MAX_GRID_LEVELS];          // 0: the level is not part of this launch
+  int32_t nparts[RC_MAX_GRID_LEVELS];
+};
+constexpr int kSliceFloats = 32768;
+constexpr int kSliceThreads = 1024;
+
+template <int F>
+__global__ __launch_bounds__(kSliceThreads) void k_grid_scatter_sliced(RcGridScatterArgs a, RcSlicedPlan plan) {
+  extern __shared__ float tab[];
+  constexpr uint32_t kEnt = kSliceFloats / F;      // entries per slice
+  int l = 0;
+  while (l + 1 < a.grid.num_levels && (int)blockIdx.x >= plan.wg_base[l + 1]) ++l;
+  const int local = (int)blockIdx.x - plan.wg_base[l];
+  const int slice = local % plan.nslice[l], part = local / plan.nslice[l];
+  const RcGridLevel L = a.grid.lvl[l];
+  const uint32_t lo = (uint32_t)slice * kEnt;
+  const uint32_t cnt = L.entries - lo < kEnt ? L.entries - lo : kEnt;      // entries of this slice
+  const int count = (int)cnt * F;
+  for (int i = threadIdx.x; i < count; i += kSliceThreads) tab[i] = 0.0f;
+  __syncthreads();
+  const int64_t per = (a.n + plan.nparts[l] - 1) / plan.nparts[l];
+  const int64_t p0 = (int64_t)part * per, p1 = p0 + per < a.n ? p0 + per : a.n;
+  const float N = (float)L.size;
+  const int LF = a.grid.num_levels * F;
+  for (int64_t p = p0 + threadIdx.x; p < p1; p += kSliceThreads) {
+    float x = a.points[3 * p], y = a.points[3 * p + 1], z = a.points[3 * p + 2];
+    if (a.contract_radius > 0.0f) contract3(x, y, z, a.contract_radius);
+    float df[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+      df[f] = (a.point_major ? a.dfeat[p * LF + l * F + f] : a.dfeat[(int64_t)(l * F + f) * a.ld + p]) * a.grid.precondition;
+    const float cx = unit_box(a.grid.bbox, x) * N, cy = unit_box(a.grid.bbox, y) * N, cz = unit_box(a.grid.bbox, z) * N;
+    float cw[3], fw[3];
+    int base[3];
+    if (L.dense) {
+      const float loc[3] = {(cz - 0.5f) + 1.0f, (cy - 0.5f) + 1.0f, (cx - 0.5f) + 1.0f};
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) { const float fl = floorf(loc[ax]); cw[ax] = loc[ax] - fl; fw[ax] = 1.0f - cw[ax]; base[ax] = (int)fl; }
+    } else {
+      const float loc[3] = {cx - 0.5f, cy - 0.5f, cz - 0.5f};
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) { const float fl = floorf(loc[ax]); cw[ax] = loc[ax] - fl; fw[ax] = 1.0f - cw[ax]; base[ax] = (int)fl; }
+    }
+#pragma unroll
+    for (int cnr = 0; cnr < 8; ++cnr) {
+      const int b0 = (cnr >> 2) & 1, b1 = (cnr >> 1) & 1, b2 = cnr & 1;
+      const float w = ((b0 ? cw[0] : fw[0]) * (b1 ? cw[1] : fw[1])) * (b2 ? cw[2] : fw[2]);
+      uint32_t idx;
+      if (L.dense) {
+        const int k0 = min(max(base[0] + b0, 0), L.size + 1), k1 = min(max(base[1] + b1, 0), L.size + 1),
+                  k2 = min(max(base[2] + b2, 0), L.size + 1);
+        if ((k0 < 1) | (k0 > L.size) | (k1 < 1) | (k1 > L.size) | (k2 < 1) | (k2 > L.size)) continue;   // zero padding
+        idx = ((uint32_t)(k2 - 1) * (uint32_t)L.size + (uint32_t)(k1 - 1)) * (uint32_t)L.size + (uint32_t)(k0 - 1);
+      } else {
+        idx = (((uint32_t)base[0] + (uint32_t)b0) ^ (((uint32_t)base[1] + (uint32_t)b1) * kPi2) ^
+               (((uint32_t)base[2] + (uint32_t)b2) * kPi3)) & L.mask;
+      }
+      if (idx - lo < cnt) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) unsafeAtomicAdd(&tab[(idx - lo) * F + f], w * df[f]);
+      }
+    }
+  }
+  __syncthreads();
+  float* __restrict__ gt = a.gtable[l] + (size_t)lo * F;
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < count; i += kSliceThreads) {      // count is a multiple of 64 (checked by the host)
+    const float v = tab[i];
+    const unsigned long long nz = __ballot(v != 0.0f);
+    if ((nz >> (lane & 48)) & 0xFFFFull) unsafeAtomicAdd(gt + i, v);          // whole 64-byte rows (k_grid_scatter_small)
   }
 }
 
@@ -418,22 +509,93 @@ void rc_launch_wgrad(RcWgradArgs a, int K, float* grads, hipStream_t stream) {
   hipLaunchKernelGGL(k_grad_reduce, dim3((kPartBO + 16) / 16), dim3(256), 0, stream, a.partial, nwaves / 4, K, grads);
 }
 
-void rc_launch_grid_scatter(const RcGridScatterArgs& a, hipStream_t stream) {
+// LDS opt-in of the scatter kernels beyond 64 KiB, once per device (not from inside a stream capture: rc_density_backward
+// calls it before it captures).  false: the opt-in was refused, the callers keep to the kernels that need none.
+bool rc_train_prepare() {
+  static std::atomic<uint64_t> prepared{0}, good{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (rc_first_use_on_device(prepared)) {
+    const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter_sliced<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kSliceFloats * 4) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter_sliced<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kSliceFloats * 4) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter_small<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter_small<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    if (ok) good.fetch_or(bit);
+  }
+  return (good.load() & bit) != 0;
+}
+
+void rc_launch_grid_scatter(const RcGridScatterArgs& a, hipStream_t stream, hipStream_t small_stream, bool use_small_stream) {
+  const hipStream_t sst = use_small_stream ? small_stream : stream;
   if (a.n <= 0) return;
   const int G = a.grid.num_features == 4 ? 4 : 2;
   dim3 grid((unsigned)((a.n * G + 255) / 256), (unsigned)a.grid.num_levels), block(256);
+  static const bool sliced_on = !(getenv("RC_SCATTER_SLICED") && getenv("RC_SCATTER_SLICED")[0] == '0');
+  const int F = a.grid.num_features;
+  uint32_t sliced_levels = 0;
+  // RC_SCATTER_SLICED=4: also the dense levels of an F = 4 grid (experiment: measured slower, below)
+  static const bool sliced_f4 = getenv("RC_SCATTER_SLICED") && getenv("RC_SCATTER_SLICED")[0] == '4';
+  if ((F == 1 || (F == 4 && sliced_f4)) && sliced_on && rc_train_prepare()) {
+    // through k_grid_scatter_sliced: every level of an F = 1 grid (power-of-two hash tables).  The dense levels of an F = 4
+    // grid (4-32 adds per row at 32 768 samples) were tried too: 37 slices, every point walked once per slice with four
+    // LDS adds per corner -- the level-2 call went from 0.199 to 0.280 ms; they stay with k_grid_scatter<4> / _small<4>.
+    int big_slices = 0, n_small = 0;
+    RcSlicedPlan plan{};
+    for (int l = 0; l < a.grid.num_levels; ++l) {
+      const RcGridLevel& L = a.grid.lvl[l];
+      const int64_t floats = (int64_t)L.entries * F;
+      const bool take = floats % 64 == 0 && (L.dense ? floats <= (1 << 20) : (F == 1 && L.mask != 0));
+      if (!take) continue;
+      sliced_levels |= 1u << l;
+      plan.nslice[l] = (int)((floats + kSliceFloats - 1) / kSliceFloats);
+      if (plan.nslice[l] > 1) big_slices += plan.nslice[l]; else ++n_small;
+    }
+    if (sliced_levels) {
+      // about one workgroup per CU (128 KiB of LDS each): big tables 2-4 point ranges per slice, one-slice tables (heavy
+      // reuse, their LDS adds are the long pole) what is left, 4-32 ranges each
+      const int cus = rc_device_cus();
+      int pb = big_slices ? (cus - cus / 8) / big_slices : 1;
+      pb = pb < 2 ? 2 : (pb > 4 ? 4 : pb);
+      int ps = n_small ? (cus - big_slices * pb) / n_small : 1;
+      ps = ps < 4 ? 4 : (ps > 32 ? 32 : ps);
+      int wg = 0;
+      for (int l = 0; l < a.grid.num_levels; ++l) {
+        plan.wg_base[l] = wg;
+        plan.nparts[l] = plan.nslice[l] > 1 ? pb : ps;
+        wg += plan.nslice[l] * plan.nparts[l];
+      }
+      for (int l = a.grid.num_levels; l <= RC_MAX_GRID_LEVELS; ++l) plan.wg_base[l] = wg;
+      const bool all = sliced_levels == (1u << a.grid.num_levels) - 1u;
+      const hipStream_t q = all ? stream : sst;      // beside the other levels' scatter when there are any
+      if (F == 4) hipLaunchKernelGGL(k_grid_scatter_sliced<4>, dim3((unsigned)wg), dim3(kSliceThreads), kSliceFloats * 4, q, a, plan);
+      else hipLaunchKernelGGL(k_grid_scatter_sliced<1>, dim3((unsigned)wg), dim3(kSliceThreads), kSliceFloats * 4, q, a, plan);
+      if (all) return;
+    }
+  }
   RcGridScatterArgs b = a;
   b.level0 = 0;
-  b.lds_levels = 0;
+  b.lds_levels = sliced_levels;
+  // experiment switches (timing only): RC_SCATTER_SKIP = bit mask of levels whose gradient is NOT computed;
+  // RC_SCATTER_LDS_MAX = largest table (floats) summed in LDS (default 32768 = 128 KiB: 16^3 at F = 1 | 4, 32^3 at F = 1)
+  static const unsigned skip_levels = getenv("RC_SCATTER_SKIP") ? (unsigned)strtoul(getenv("RC_SCATTER_SKIP"), nullptr, 0) : 0u;
+  static const int64_t lds_max = getenv("RC_SCATTER_LDS_MAX") ? atoll(getenv("RC_SCATTER_LDS_MAX")) : 32768;
   for (int l = 0; l < a.grid.num_levels; ++l) {
     const RcGridLevel& L = a.grid.lvl[l];
-    if (!L.dense || (int64_t)L.entries * a.grid.num_features > 16384) continue;
-    b.lds_levels |= 1u << l;
+    if ((sliced_levels >> l) & 1u) continue;
+    if ((skip_levels >> l) & 1u) { b.lds_levels |= 1u << l; continue; }
+    if (!L.dense || (int64_t)L.entries * a.grid.num_features > lds_max) continue;
     const int lds = (int)L.entries * a.grid.num_features * (int)sizeof(float);
+    if (lds > 65536 && !rc_train_prepare()) continue;       // no LDS opt-in: the level goes through the global scatter
+    b.lds_levels |= 1u << l;
     int wgs = (int)((a.n + 255) / 256);            // one table flush per workgroup: at most one per CU
     if (wgs > 256) wgs = 256;
-    if (a.grid.num_features == 4) hipLaunchKernelGGL((k_grid_scatter_small<4>), dim3(wgs), dim3(256), lds, stream, b, l);
-    else hipLaunchKernelGGL((k_grid_scatter_small<1>), dim3(wgs), dim3(256), lds, stream, b, l);
+    if (lds > 65536) {                              // beyond the default LDS limit
+      static const int wg_big = getenv("RC_SCATTER_BIG_WGS") ? atoi(getenv("RC_SCATTER_BIG_WGS")) : 256;
+      if (wgs > wg_big) wgs = wg_big;               // (experiment knob; 16 ... 256 workgroups measured: 256 is the fastest)
+    }
+    if (a.grid.num_features == 4) hipLaunchKernelGGL((k_grid_scatter_small<4>), dim3(wgs), dim3(256), lds, sst, b, l);
+    else hipLaunchKernelGGL((k_grid_scatter_small<1>), dim3(wgs), dim3(256), lds, sst, b, l);
   }
   const RcGridScatterArgs& a2 = b;
   if (a.grid.num_features == 4) hipLaunchKernelGGL((k_grid_scatter<4>), grid, block, 0, stream, a2);

@@ -382,6 +382,8 @@ class RadianceCache:
         dtype = dtype or torch.float32
         if not isinstance(x, torch.Tensor):
             x = torch.from_numpy(np.ascontiguousarray(x))
+        elif x.is_cuda and x.dtype == dtype and x.is_contiguous() and x.device.index == self.device:
+            return x                    # already where and how the library wants it (the per-call path of a training loop)
         return x.to(device=f"cuda:{self.device}", dtype=dtype).contiguous()
 
     def render_rays(self, rays: Dict[str, object], randoms: Optional[Dict[str, object]] = None,
@@ -604,9 +606,13 @@ class RadianceCache:
         df = None
         if d_feature is not None:
             df = self._dev(d_feature).reshape(n, 64).contiguous()
-        total = int(self.lib.rc_density_grad_size(self._h, level))
-        if total < 0:
-            self._check(total)
+        sizes = self.__dict__.setdefault("_grad_sizes", {})        # the layout is fixed by the config: asked once per level
+        total = sizes.get(level)
+        if total is None:
+            total = int(self.lib.rc_density_grad_size(self._h, level))
+            if total < 0:
+                self._check(total)
+            sizes[level] = total
         if grads is None:
             grads = torch.zeros(total, dtype=torch.float32, device=f"cuda:{self.device}")
         elif grads.numel() != total or grads.dtype != torch.float32 or not grads.is_cuda or not grads.is_contiguous():
