@@ -31,11 +31,17 @@ template <int F> struct Vec;
 template <> struct Vec<1> { float v[1]; };
 template <> struct Vec<4> { float v[4]; };
 
+#ifdef RC_GATHER_FAKE
+// timing experiment (tools/fused_critical_path.py): every lookup goes to the same few entries -- the lookups' issue time
+// without their memory time.  The mask passes through an empty asm so that the index arithmetic in front of it stays.
+__device__ __forceinline__ uint32_t fake_mask() { uint32_t m = RC_GATHER_FAKE; asm volatile("" : "+s"(m)); return m; }
+#endif
+
 template <int F>
 __device__ __forceinline__ Vec<F> load_entry(const float* __restrict__ table, uint32_t idx) {
   Vec<F> r;
 #ifdef RC_GATHER_FAKE
-  idx &= RC_GATHER_FAKE;
+  idx &= fake_mask();
 #endif
   if constexpr (F == 4) {
     const float4 q = reinterpret_cast<const float4*>(table)[idx];
@@ -261,7 +267,10 @@ template <int KIND>
 __device__ __forceinline__ void half_corners(const float* __restrict__ table, int size, uint32_t mask, int h, float x01,
                                              float y01, float z01, float (&cw)[3], float (&v)[4]) {
   if constexpr (KIND == kLevelCell || KIND == kLevelHRec) {
-    const uint32_t cell = KIND == kLevelCell ? cell_index(size, x01, y01, z01, cw) : hrec_index(size, x01, y01, z01, cw);
+    uint32_t cell = KIND == kLevelCell ? cell_index(size, x01, y01, z01, cw) : hrec_index(size, x01, y01, z01, cw);
+#ifdef RC_GATHER_FAKE
+    cell &= fake_mask();
+#endif
     const f32x4 q = *reinterpret_cast<const f32x4*>(table + (size_t)cell * 8 + 4 * h);
     v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
   } else {
@@ -280,7 +289,11 @@ __device__ __forceinline__ void half_corners(const float* __restrict__ table, in
     const uint32_t y0 = (uint32_t)base[1] * kPi2, z0 = (uint32_t)base[2] * kPi3;
     const uint32_t hy[2] = {y0, y0 + kPi2}, hz[2] = {z0, z0 + kPi3};
 #pragma unroll
+#ifdef RC_GATHER_FAKE
+    for (int c = 0; c < 4; ++c) v[c] = table[(hx ^ hy[(c >> 1) & 1] ^ hz[c & 1]) & mask & fake_mask()];
+#else
     for (int c = 0; c < 4; ++c) v[c] = table[(hx ^ hy[(c >> 1) & 1] ^ hz[c & 1]) & mask];
+#endif
   }
 }
 

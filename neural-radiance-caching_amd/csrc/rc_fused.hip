@@ -558,7 +558,8 @@ void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream) {
 #ifdef RC_STAMPS
   {
     static unsigned long long* buf = nullptr; static int64_t cap = 0;
-    if (cap < L.n) { if (buf) (void)hipFree(buf); (void)hipMalloc((void**)&buf, (size_t)L.n * 16 * 8); cap = L.n; }
+    // 2 x: the two-wave kernel keeps the stamps of a ray's second wave at [n + ray]
+    if (cap < L.n) { if (buf) (void)hipFree(buf); (void)hipMalloc((void**)&buf, (size_t)L.n * 2 * 16 * 8); cap = L.n; }
     a.stamps = buf; g_fused_stamps = buf;
   }
 #endif

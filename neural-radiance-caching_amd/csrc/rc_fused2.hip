@@ -738,12 +738,21 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
       const int id = lane == 0 ? RC_OUT_DISTANCE_PERCENTILE_5 : (lane == 1 ? RC_OUT_DISTANCE_MEDIAN : RC_OUT_DISTANCE_PERCENTILE_95);
       if (a.out.ptr[id]) a.out.ptr[id][ray] = pv;
     }
+#ifdef RC_STAMPS
+    RC_FSTAMP(11);
+    if (lane == 0 && a.stamps && ray_ok) {          // wave 1 of a ray: second half of the stamp buffer
+      unsigned long long* d = a.stamps + (ray + a.n) * 16;
+      for (int i = 0; i < 12; ++i) d[i] = stamps[i];
+      d[14] = rt0; d[15] = __builtin_amdgcn_s_memrealtime();
+      d[12] = tb_wait; d[13] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | (tb_count << 32);
+    }
+#endif
     return;
   }
   RC_FSTAMP(11);
 #ifdef RC_STAMPS
   if (lane == 0 && a.stamps && ray_ok) {
-    unsigned long long* d = a.stamps + ray * 16;
+    unsigned long long* d = a.stamps + (ray + (q ? a.n : 0)) * 16;      // wave 1 of a ray: second half of the buffer
     for (int i = 0; i < 12; ++i) d[i] = stamps[i];
     d[14] = rt0; d[15] = __builtin_amdgcn_s_memrealtime();
     d[12] = tb_wait; d[13] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | (tb_count << 32);

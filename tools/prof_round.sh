@@ -1,7 +1,8 @@
 #!/bin/bash
 # Profiling session of a round (run on the GPU box through gpurun, from the repo root): kernel traces of the default
 # bench (fused plan), of the staged plan and of the material stage, PMC passes (each in its own run, kernel-trace only),
-# the in-kernel phase stamps of the fused kernel (needs `make -C neural-radiance-caching_amd/csrc diag` beforehand).
+# the in-kernel phase stamps of the fused kernel (needs `make -C neural-radiance-caching_amd/csrc diag` beforehand; with
+# `make ... diag DIAG_EXTRA=-DRC_GATHER_FAKE=0 DIAG_DIR=fake` as well, the per-phase critical-path table).
 # Everything lands under gpurun_out/prof_$1; copy what is to be kept into profiles/.
 set -e
 R=${1:-r02}
@@ -42,5 +43,10 @@ if [ -f tools/diag/librc_hip.so ]; then
   RC_STAMP_RAYS=tile python tools/gpu_stamps_fused.py 1024 "" $O/fused_phase_stamps_tile.json > $O/fused_phase_stamps_tile.txt
   RC_STAMP_RAYS=strip python tools/gpu_stamps_fused.py 1024 "" $O/fused_phase_stamps_strip.json > $O/fused_phase_stamps_strip.txt
   echo "stamps done"
+fi
+if [ -f tools/diag/librc_hip.so ] && [ -f tools/diag/fake/librc_hip.so ]; then
+  # per-phase / per-wave critical path of the fused kernel: stamped build against the stamped build without memory time
+  python tools/fused_critical_path.py > $O/fused_critical_path.txt
+  echo "critical path done"
 fi
 find $O -name "*.csv" | sort
