@@ -363,11 +363,13 @@ int build_fused_tables(rc_handle* h) {
         const RcGridLevel& L = h->grids[g].dev.lvl[l];
         if (!L.dense) {
           // the first hashed levels of the F = 1 grids as cell records (kLevelHRec): (N + 1)^3 records of 8 floats
-          if (g < 2 && l < kRcFusedDenseLevels + kRcRecLevels && L.mask != 0) {
+          const int nrl = g < 2 ? kRcRecLevels : kRcRec4Levels;      // g == 2: the F = 4 density grid (level kernels' lean pass)
+          if (l < kRcFusedDenseLevels + nrl && L.mask != 0) {
+            const int F = h->grids[g].dev.num_features;
             const size_t nrec = (size_t)(L.size + 1) * (L.size + 1) * (L.size + 1);
             float* dst = nullptr;
-            if ((rc = cells("rec" + std::to_string(g) + "_" + std::to_string(l), nrec * 8, &dst))) return rc;
-            rc_launch_build_hrec(L.table, L.size, L.mask, dst, nullptr);
+            if ((rc = cells("rec" + std::to_string(g) + "_" + std::to_string(l), nrec * 8 * F, &dst))) return rc;
+            rc_launch_build_hrec(L.table, L.size, L.mask, F, dst, nullptr);
             h->grids[g].dev.lvl[l].rec = dst;
           }
           continue;
@@ -411,11 +413,31 @@ void build_fused_template(rc_handle* h) {
 
 // The handle's side stream (work that only feeds a call's outputs, forked from / joined to the caller's stream with events)
 // at the lowest priority: the kernels on the caller's stream -- the critical path -- get the CUs first.
+// Helper streams are per PROCESS and device, created together by the first rc_create and never destroyed: [0] lowest
+// priority (the material stage's side work), [1], [2] highest priority (rc_density_backward).  Measured on this runtime
+// (ROCm 7.2, profiles/r04_helper_streams.txt): with streams that come and go with their handles, whichever multi-stream
+// call ran SECOND in a process was slow -- every kernel of the call +50 us or 2-3x, ~100 us of host time between calls:
+// bench.py's train line after its material line 0.20 -> 0.37 ms per level-2 call, the other order the material stage
+// 1.39 -> 1.95 ms.  Sharing the streams across handles did not cure it, creating all of them before any work did.
+// Handles are driven by one host thread per GPU; every call forks from and joins to the caller's stream with the
+// handle's own events, so sharing the streams only orders the helper work of two handles.
+hipStream_t rc_helper_stream(int which) {
+  static hipStream_t pool[64][3] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  hipStream_t& s = pool[dev & 63][which];
+  if (!s) {
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, which == 0 ? prio_lo : prio_hi) != hipSuccess) s = nullptr;
+  }
+  return s;
+}
+
 int ensure_side_stream(rc_handle* h) {
   if (h->side_stream) return RC_OK;
-  int prio_lo = 0, prio_hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  RC_HIP(h, hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio_lo));
+  h->side_stream = rc_helper_stream(0);
+  if (!h->side_stream) return fail(h, RC_ERR_HIP, "side stream");
   for (hipEvent_t& e : h->ev_side) RC_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   return RC_OK;
 }
@@ -803,6 +825,9 @@ int rc_create(const rc_config* cfg, int device, rc_handle** out) {
   rc_handle* h = hp.get();
   h->cfg = *cfg;
   h->device = device;
+  // all helper streams of the process now, in a fixed order, before any work (rc_helper_stream: a low-priority stream
+  // first created AFTER the high-priority ones had run took the material stage from 1.39 to 1.95 ms)
+  for (int i = 0; i < 3; ++i) (void)rc_helper_stream(i);
   const rc_grid_config* gcfgs[6] = {&cfg->proposal_grids[0], &cfg->proposal_grids[1], &cfg->proposal_grids[2],
                                     &cfg->appearance_grid, &cfg->material_grid, &cfg->light_grid};
   const char* prefixes[6] = {"params/Cache/Sampler/MLP_0/density_grid", "params/Cache/Sampler/MLP_1/density_grid",
@@ -847,8 +872,7 @@ void rc_destroy(rc_handle* h) {
   drop_graphs(h);
   for (auto& G : h->groups) if (G.done) (void)hipEventDestroy(G.done);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
-  if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
-  for (hipStream_t s : h->train_stream) if (s) (void)hipStreamDestroy(s);
+  // side_stream / train_stream belong to the process (rc_helper_stream)
   for (hipEvent_t e : h->ev_train) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_side) if (e) (void)hipEventDestroy(e);
   if (h->ev_created)

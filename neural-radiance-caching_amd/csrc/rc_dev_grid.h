@@ -133,9 +133,12 @@ __device__ __forceinline__ void grid_fetch_cell(const float* __restrict__ cell_t
 // wave-loads back to back from every wave queue up in front of the texture-address unit; spaced by their index arithmetic
 // they interleave with the other waves' (profiles/r04_bisect_hashgrid_standalone.txt: `abold` = this header's
 // predecessor under HEAD's library).
+// `rec` (may differ per lane, like `dense`): `table` is the level's cell-record table (hrec_index below; a hashed level whose
+// 8 corner entries sit side by side per cell origin) -- the eight indices are then record * 8 + corner.
+__device__ __forceinline__ uint32_t hrec_index(int size, float x01, float y01, float z01, float (&cw)[3]);
 template <int F, bool POW2 = false, int STRIDE = 1, bool CELL = false, bool UNIFORM = false>
 __device__ __forceinline__ void grid_fetch(const float* __restrict__ table, int size, uint32_t mask, uint32_t entries,
-                                           bool dense, float x01, float y01, float z01, Corners<F>& C) {
+                                           bool dense, float x01, float y01, float z01, Corners<F>& C, bool rec = false) {
   C.zero_mask = 0;
   uint32_t idx[8];
   // fetch order: the two corners that differ in b0 -- x and x + 1: adjacent entries of a dense level, an index that
@@ -157,7 +160,10 @@ __device__ __forceinline__ void grid_fetch(const float* __restrict__ table, int 
       for (int c = 0; c < 8; ++c) idx[c] = index_of(c);
     }
   };
-  if (dense) {
+  if (rec) {
+    const uint32_t r8 = hrec_index(size, x01, y01, z01, C.cw) * 8u;
+    visit([&](int c) { return r8 + (uint32_t)c; });
+  } else if (dense) {
     if constexpr (CELL) {
       const uint32_t cell = cell_index(size, x01, y01, z01, C.cw);
       visit([&](int c) { return cell * 8u + (uint32_t)c; });

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_hashgrid_pair(RcGridDev g, RcPairTables
 }
 
 // Cell records of a hashed F = 1 level (rc_internal.h rc_launch_build_hrec): one thread per (record, corner).
-__global__ __launch_bounds__(256) void k_build_hrec(const float* __restrict__ table, int N, uint32_t mask, float* __restrict__ dst) {
+__global__ __launch_bounds__(256) void k_build_hrec(const float* __restrict__ table, int N, uint32_t mask, int F, float* __restrict__ dst) {
   const int64_t M = N + 1, total = M * M * M * 8;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -120,14 +120,15 @@ __global__ __launch_bounds__(256) void k_build_hrec(const float* __restrict__ ta
   const int qz = (int)(r % M), qy = (int)((r / M) % M), qx = (int)(r / (M * M));
   // int32 -> uint32 wraparound hash of the corner (grid_utils.py:99-111), as grid_fetch computes it
   const uint32_t px = (uint32_t)(qx - 1 + ((c >> 2) & 1)), py = (uint32_t)(qy - 1 + ((c >> 1) & 1)), pz = (uint32_t)(qz - 1 + (c & 1));
-  dst[i] = table[(px ^ (py * kPi2) ^ (pz * kPi3)) & mask];
+  const uint32_t e = (px ^ (py * kPi2) ^ (pz * kPi3)) & mask;
+  for (int f = 0; f < F; ++f) dst[i * F + f] = table[(size_t)e * F + f];
 }
 
 }  // namespace
 
-void rc_launch_build_hrec(const float* table, int N, uint32_t mask, float* dst, hipStream_t stream) {
+void rc_launch_build_hrec(const float* table, int N, uint32_t mask, int F, float* dst, hipStream_t stream) {
   const int64_t total = (int64_t)(N + 1) * (N + 1) * (N + 1) * 8;
-  hipLaunchKernelGGL(k_build_hrec, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, table, N, mask, dst);
+  hipLaunchKernelGGL(k_build_hrec, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, table, N, mask, F, dst);
 }
 
 void rc_launch_hashgrid_src(const RcGridDev& g, const float* points, int soa_in, const int32_t* src, int64_t n_src,

@@ -41,8 +41,9 @@ struct RcGridLevel {
   uint32_t mask;        // T-1 if T is a power of two, else 0
   const float* cell;    // dense F = 1 levels of the proposal grids: cell table ((N+3)^3 cells x 8 corners, zero padding
                         // baked in; built with the fused kernel's tables) or nullptr
-  const float* rec;     // hashed F = 1 levels [kRcFusedDenseLevels, + kRcRecLevels) of the proposal grids: cell records
-                        // ((N+1)^3 cell origins x the 8 hashed corner values, rc_launch_build_hrec) or nullptr
+  const float* rec;     // hashed levels [kRcFusedDenseLevels, + kRcRecLevels) of the F = 1 proposal grids, [.., + kRcRec4Levels)
+                        // of the F = 4 density grid: cell records ((N+1)^3 cell origins x the 8 hashed corner entries,
+                        // rc_launch_build_hrec) or nullptr
 };
 
 struct RcGridDev {
@@ -312,9 +313,18 @@ constexpr int kRcFusedDenseLevels = 3;
 #define RC_REC_LEVELS 1
 #endif
 constexpr int kRcRecLevels = RC_REC_LEVELS;
+// The same for the F = 4 density grid of the last level, which the level kernels read on the lean pass (density of all
+// 32 samples of a secondary ray before one is picked): its hashed tables are 8 MiB each, 40 MiB together -- every sector
+// is a fabric read there (k_level_ray<4, 8, 32>: 22 M L2 misses per 32 768-ray trace, the memory system's random-sector
+// rate), and a 128-byte record (8 corners x 16 bytes = one cache line) replaces ~4.4 sectors by 2.
+// 275 MB for the 128^3 level, 2.2 GB for 256^3.
+#ifndef RC_REC4_LEVELS
+#define RC_REC4_LEVELS 2
+#endif
+constexpr int kRcRec4Levels = RC_REC4_LEVELS;
 // dst[(N+1)^3][8]: record (qx, qy, qz) in [0, N]^3 = cell origin (qx - 1, qy - 1, qz - 1), corner c = 4 b0 + 2 b1 + b2 at
 // origin + (b0, b1, b2) through the level's hash (power-of-two table)
-void rc_launch_build_hrec(const float* table, int N, uint32_t mask, float* dst, hipStream_t stream);
+void rc_launch_build_hrec(const float* table, int N, uint32_t mask, int F, float* dst, hipStream_t stream);
 int rc_fused_stream_offsets(int* l0, int* l1, int* l2, int* sh);   // returns the total fragment count
 void rc_launch_fused(const RcFusedLaunch& L, hipStream_t stream);
 // dst[cell][corner][dst_stride floats, written F at dst_off]: the 8 corners of every cell of the zero-padded dense

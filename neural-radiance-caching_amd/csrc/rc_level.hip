@@ -161,10 +161,12 @@ struct LevelK {
                 grid_fetch<1, true, 1, true>(tab, size, mask, 0u, pick_half(h, k0, k1) == 2, ux, uy, uz, C[ii]);
               }
             } else {
-              const bool d0 = L0.dense != 0, d1 = L1.dense != 0;
-              const float* tab = pick_half(h, L0.table, L1.table);
-              if (d0 == d1) grid_fetch<4, true>(tab, size, mask, 0u, d0, ux, uy, uz, C[ii]);
-              else grid_fetch<4, true>(tab, size, mask, 0u, pick_half(h, d0, d1), ux, uy, uz, C[ii]);
+              // kind of a level: dense | hashed | hashed through its cell records (L.rec: 128 bytes per cell origin = one
+              // cache line for the eight corners instead of ~4.4 sectors of the 8 MiB table)
+              const bool d0 = L0.dense != 0, d1 = L1.dense != 0, r0 = L0.rec != nullptr, r1 = L1.rec != nullptr;
+              const float* tab = pick_half(h, r0 ? L0.rec : L0.table, r1 ? L1.rec : L1.table);
+              if (d0 == d1 && r0 == r1) grid_fetch<4, true>(tab, size, mask, 0u, d0, ux, uy, uz, C[ii], r0);
+              else grid_fetch<4, true>(tab, size, mask, 0u, pick_half(h, d0, d1), ux, uy, uz, C[ii], pick_half(h, r0, r1));
             }
           }
         }
