@@ -578,8 +578,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
         const float ref = fmaxf(softplus_bins(1.0f * as[r] + a.slf_rgb_bias), 0.0f);
 #endif
         float spec = (tib * ref) * a.indirect_scale;
-        diff = live ? fminf(fmaxf(diff, 0.0f), a.rgb_max) : 0.0f;             // nerf.py:1757-1758
-        spec = live ? fminf(fmaxf(spec, 0.0f), a.rgb_max) : 0.0f;
+        // jnp.clip(x, 0, rgb_max) (nerf.py:1757-1758) as ONE v_med3_f32: the median of (x, 0, rgb_max) is the clamp for
+        // 0 <= rgb_max and an ordered x (softplus >= 0 is never NaN here); fmaxf + fminf were two instructions plus a
+        // canonicalising v_max of the scalar bound each
+        diff = live ? __builtin_amdgcn_fmed3f(diff, 0.0f, a.rgb_max) : 0.0f;
+        spec = live ? __builtin_amdgcn_fmed3f(spec, 0.0f, a.rgb_max) : 0.0f;
         sdu[r] += diff; ssu[r] += spec;
         cd += w * diff; cs += w * spec;
         const float val = w * (diff + spec);
@@ -673,8 +676,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
   //      The reference indexes the flattened [rays * bins] array: bins >= 700 of the previous ray of the batch
   //      land at the start of this ray's histogram.
   {
-    // lanes 0-31 prepare the samples of the previous ray, lanes 32-63 those of this ray; lanes 0-2 (one per
-    // channel) then add the 64 contributions in that order
+    // lanes 0-31 take the samples of the previous ray (their bins >= 700), lanes 32-63 those of this ray
     const int64_t sr = ray - 1 + h;
     int il = -1, ih = -1;
     float vl[3] = {0.0f, 0.0f, 0.0f}, vh[3] = {0.0f, 0.0f, 0.0f};
@@ -694,22 +696,16 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
         vl[c] = val * w_low; vh[c] = val * w_high;
       }
     }
-    auto bc_i = [](int v, int l) { return __builtin_amdgcn_readlane(v, l); };
-    auto bc_f = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+    // One LDS float add per (target kind, channel) for all 64 samples at once: lane = sample, all the low targets first,
+    // then all the high ones -- the order of the reference's two scatter-adds (render.py:453-477: `.at[indices_low].add`,
+    // then `.at[indices_high].add`).  Lanes that hit one address are served one after the other by the LDS.  (Rounds 1-3
+    // walked the 64 samples in order, eight v_readlane broadcasts and two three-lane adds each: 512 + 128 instructions.)
 #pragma unroll
-    for (int sidx = 0; sidx < 64; ++sidx) {
-      const int bl = bc_i(il, sidx), bh = bc_i(ih, sidx);
-      const float l0 = bc_f(vl[0], sidx), l1 = bc_f(vl[1], sidx), l2 = bc_f(vl[2], sidx);
-      const float h0 = bc_f(vh[0], sidx), h1 = bc_f(vh[1], sidx), h2 = bc_f(vh[2], sidx);
-      if (lane < 3) {
-        const float lo = lane == 0 ? l0 : (lane == 1 ? l1 : l2);
-        const float hi = lane == 0 ? h0 : (lane == 1 ? h1 : h2);
-        // LDS float adds (ds_add_f32): the adds of one wave to one address complete in program order, i.e. the 64
-        // contributions still arrive in sample order, without a read-add-write round trip each
-        if (bl >= 0) atomicAdd(&hist_d[bl * 3 + lane], lo);
-        if (bh >= 0) atomicAdd(&hist_d[bh * 3 + lane], hi);
-      }
-    }
+    for (int c = 0; c < 3; ++c)
+      if (il >= 0) atomicAdd(&hist_d[il * 3 + c], vl[c]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      if (ih >= 0) atomicAdd(&hist_d[ih * 3 + c], vh[c]);
   }
   lds_sync<false>();
 #ifdef RC_STAMPS
