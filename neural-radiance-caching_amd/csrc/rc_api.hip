@@ -128,6 +128,7 @@ struct rc_handle {
   hipStream_t cap_stream = nullptr;
   // rc_render_material: work that the secondary trace does not wait for (material-only composite over all samples,
   // EnvMap along the secondary rays) runs on this stream, forked from / joined to the caller's with events
+  float* sec_sbounds = nullptr;            // power-ladder image of the secondary rays' (near, far): constants of the config
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_side[4] = {nullptr, nullptr, nullptr, nullptr};
   // rc_density_backward: weight gradients ([0]) and the LDS-accumulated table levels ([1]) beside the scatter of the other
@@ -363,7 +364,10 @@ int build_fused_tables(rc_handle* h) {
         const RcGridLevel& L = h->grids[g].dev.lvl[l];
         if (!L.dense) {
           // the first hashed levels of the F = 1 grids as cell records (kLevelHRec): (N + 1)^3 records of 8 floats
-          const int nrl = g < 2 ? kRcRecLevels : kRcRec4Levels;      // g == 2: the F = 4 density grid (level kernels' lean pass)
+          // g == 2: the F = 4 density grid (level kernels' lean pass).  Its records are 2.5 GB per handle: RC_REC4_TABLES=0 in
+          // the environment leaves them out (the level kernels test L.rec at run time; the material step is 2.4 % slower)
+          static const bool rec4_on = !(getenv("RC_REC4_TABLES") && getenv("RC_REC4_TABLES")[0] == '0');
+          const int nrl = g < 2 ? kRcRecLevels : (rec4_on ? kRcRec4Levels : 0);
           if (l < kRcFusedDenseLevels + nrl && L.mask != 0) {
             const int F = h->grids[g].dev.num_features;
             const size_t nrec = (size_t)(L.size + 1) * (L.size + 1) * (L.size + 1);
@@ -873,6 +877,7 @@ void rc_destroy(rc_handle* h) {
   for (auto& G : h->groups) if (G.done) (void)hipEventDestroy(G.done);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   // side_stream / train_stream belong to the process (rc_helper_stream)
+  if (h->sec_sbounds) (void)hipFree(h->sec_sbounds);
   for (hipEvent_t e : h->ev_train) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_side) if (e) (void)hipEventDestroy(e);
   if (h->ev_created)
@@ -1575,7 +1580,7 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
       (rc = ws_alloc(h, "sec_dirs", 3 * nsec)) || (rc = ws_alloc(h, "sec_near", nsec)) || (rc = ws_alloc(h, "sec_far", nsec)) ||
       (rc = ws_alloc(h, "sec_lights", 3 * nsec)) || (rc = ws_alloc(h, "sec_samples", RC_SMP_CH * nsec)) ||
       (rc = ws_alloc(h, "m_local_view", 3 * n)) || (rc = ws_alloc(h, "sec_rgb", 3 * nsec)) ||
-      (rc = ws_alloc(h, "sec_acc", nsec)) || (rc = ws_alloc(h, "sec_env", 3 * nsec)) || (rc = ws_alloc(h, "sec_sbounds", 2)))
+      (rc = ws_alloc(h, "sec_acc", nsec)) || (rc = ws_alloc(h, "sec_env", 3 * nsec)))
     return rc;
   h->ws_prefix = "s:";
   rc = ensure_workspace(h, nsec);
@@ -1690,9 +1695,14 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     B.n = nsec; B.mask = RC_PASS_CACHE | RC_PASS_SECONDARY | RC_PASS_NO_ENVMAP; B.slot = -1;
     // every secondary ray of this trace has the same (near, far) (k_brdf_sample writes the two constants): the
     // power-ladder image of the pair is computed once instead of by each of the 3 x 32 768 sampler waves
-    rc_launch_ladder_bounds(c.secondary_near, c.secondary_far, c.env_map_distance, c.raydist_p, c.raydist_premult,
-                            W(h, "sec_sbounds"), st);
-    B.s_bounds = W(h, "sec_sbounds");
+    // ... and once per handle: the five inputs are constants of the configuration (same device function, a buffer of
+    // the handle's own; 5 us + a 6 us gap in every step before)
+    if (!h->sec_sbounds) {
+      RC_HIP(h, hipMalloc((void**)&h->sec_sbounds, 2 * sizeof(float)));
+      rc_launch_ladder_bounds(c.secondary_near, c.secondary_far, c.env_map_distance, c.raydist_p, c.raydist_premult, h->sec_sbounds, st);
+      RC_HIP(h, hipStreamSynchronize(st));       // later calls may come on other streams
+    }
+    B.s_bounds = h->sec_sbounds;
     memset(&B.out, 0, sizeof(B.out));
     B.out.ptr[RC_OUT_RGB] = W(h, "sec_rgb"); B.out.ptr[RC_OUT_ACC] = W(h, "sec_acc");
     float* sec_dirs = W(h, "sec_dirs"); float* sec_env = W(h, "sec_env");
