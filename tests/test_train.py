@@ -251,3 +251,33 @@ def test_hashgrid_backward_is_the_transpose_of_the_lookup(grid_id):
     rhs = float((tables.double() * flat.double()).sum())
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (lhs, rhs)
     assert P in names[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid_id", [0, 1])
+def test_sliced_scatter_at_batch_size_adjoint_and_level_sums(grid_id):
+    """k_grid_scatter_sliced (F = 1 grids: every level through LDS slices, whole-row flush) at the size it is built for --
+    65 536 + 37 points, every (level, slice, point range) workgroup of the plan busy -- through two size-independent
+    properties: the adjoint identity <lookup(T), d> == <T, backward(d)> with the device's own forward lookup, and, per
+    level, sum of the level's table gradient == precondition * sum of d[:, level] (the eight trilinear weights of a point
+    sum to one; the points are kept 0.05 of the box away from its faces, so no corner of a dense level is zero padding)."""
+    rc = common.make_rc()
+    n = 65536 + 37
+    pts = np.clip(_points(n, seed=41, spread=0.5), -1.8, 1.8)
+    g = rc.cfg_grid(grid_id)
+    rng = np.random.Generator(np.random.PCG64(42))
+    d = rng.normal(size=(n, g.out_dim)).astype(np.float32)
+    layout, total = rc.hashgrid_grad_layout(grid_id)
+    flat = rc.hashgrid_backward(grid_id, pts, d)
+    assert bool(torch.isfinite(flat).all())
+    names = [name for name, _, _ in layout]
+    tables = torch.cat([torch.from_numpy(common.weights_np()[name]).reshape(-1) for name in names]).cuda()
+    fwd = rc.hashgrid_lookup(grid_id, pts)
+    lhs = float((fwd.double() * torch.from_numpy(d).cuda().double()).sum())
+    rhs = float((tables.double() * flat.double()).sum())
+    assert abs(lhs - rhs) <= 2e-4 * max(1.0, abs(lhs)), (lhs, rhs)
+    dsum = torch.from_numpy(d).double().sum(0).numpy()
+    for l, (name, off, shape) in enumerate(layout):
+        got = float(flat[off: off + int(np.prod(shape))].double().sum())
+        want = float(g.precondition_scaling * dsum[l])
+        assert abs(got - want) <= 2e-3 * max(1.0, float(np.abs(d[:, l]).sum()) * g.precondition_scaling * 1e-3), (name, got, want)
