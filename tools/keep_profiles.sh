@@ -12,6 +12,8 @@ cp $O/staged/staged_kernel_stats.csv profiles/${R}_kernel_stats_staged_plan.csv
 cp $O/fused1/fused1_kernel_stats.csv profiles/${R}_kernel_stats_one_wave_per_ray.csv
 cp $O/material/material_kernel_stats.csv profiles/${R}_material_kernel_stats.csv
 cp $O/material_pmc_counters.txt profiles/${R}_material_pmc_counters.txt
+[ -f $O/train/train_kernel_stats.csv ] && cp $O/train/train_kernel_stats.csv profiles/${R}_train_backward_kernel_stats.csv
+[ -f $O/fused_critical_path.txt ] && cp $O/fused_critical_path.txt profiles/${R}_fused_critical_path.txt
 python tools/prof_summary.py $O > profiles/${R}_summary.txt
 python -c "
 import json, nrc_amd

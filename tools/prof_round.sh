@@ -20,6 +20,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/staged -o staged -- $
 echo "staged trace done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/material -o material -- python $ROOT/tools/bench_material.py > $O/bench_material.txt 2> $O/material.err
 echo "material trace done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o train -- python $ROOT/tools/bench_train.py > $O/bench_train.txt 2> $O/train.err
+echo "train-backward trace done"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
