@@ -21,7 +21,9 @@ here, separate pass on the launch-per-stage plan) and of the gather phases insid
 of a diagnostic build, profiles/, same staleness rule).  `parity` is max |rgb - oracle| and the PSNR of the first batch.
 `image` times BASELINE configs[3]: the 800 x 800 image, rays sharded over the ranks (strong scaling), one all-gather.
 `cpu_baseline` times the CPU oracle (a torch fp32 restatement of the reference path, kind "port":
-the JAX reference cannot run here) on a bounded sample of the same workload.
+the JAX reference cannot run here) on the same 1024-ray batch by BASELINE.md's protocol: 8 threads and all granted host
+cores, 3 warm-up + 10 timed passes each, median (`cpu_baseline.runs` holds both, `value` the all-cores run).
+`image.ms_per_image_to_host` adds the one device-to-host copy of the gathered keys to the device-complete image time.
 """
 import argparse
 import json

@@ -30,7 +30,15 @@ using namespace rcfused;
 
 namespace {
 
-constexpr int kTW = 4;                        // waves per workgroup: 2 rays x 2 waves
+// Rays per workgroup.  2 (the product): 4 waves, 79.8 KiB of LDS, TWO workgroups per CU, each with its own 24 KiB ring.
+// 4 (experiment, VERDICT r3 item 4: `make diag DIAG_EXTRA="-DRC_TEAM_RAYS=4 -DRC_TCH=96"`): ONE workgroup of 8 waves per
+// CU on ONE ring of 48 KiB -- the weight stream crosses L2 -> LDS once per CU instead of twice and has half the seams, but
+// every hand-off and seam is then a barrier of eight waves (four rays in lockstep).  Measured: profiles/r04_team_rays.txt.
+#ifndef RC_TEAM_RAYS
+#define RC_TEAM_RAYS 2
+#endif
+constexpr int kRays = RC_TEAM_RAYS;
+constexpr int kTW = 2 * kRays;                // waves per workgroup: kRays rays x 2 waves
 #ifndef RC_TCH
 #define RC_TCH 48
 #endif
@@ -221,20 +229,22 @@ __device__ __forceinline__ float level_tile(const RcFusedArgs& a, const WStream&
 }
 
 template <bool GRAD>
-__global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a) {
+__global__ __launch_bounds__(kTW * 64, kRays == 2 ? 2 : 1) void k_cache_fused_team(RcFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   // ray slot of the workgroup, role half of the ray.  Wave 0 of a ray carries the single-wave phases (scans, heads,
   // compositing): prio_mode bit 3 (experiment) swaps the roles in the second half of the grid, so that a SIMD shared by
   // two workgroups does not host two such waves (waves go to SIMDs by their index)
-  const int rs = wave & 1;
-  const int q = (wave >> 1) ^ (((a.prio_mode & 8) && blockIdx.x >= (gridDim.x >> 1)) ? 1 : 0);
-  int64_t ray = (int64_t)blockIdx.x * 2 + rs;
+  // kRays == 4: waves w and w + 4 share a SIMD -- (ray, role) = ((w + w / 4) % 4, w / 4) puts two DIFFERENT rays in
+  // different roles there
+  const int rs = kRays == 2 ? (wave & 1) : ((wave + (wave >> 2)) & 3);
+  const int q = kRays == 2 ? ((wave >> 1) ^ (((a.prio_mode & 8) && blockIdx.x >= (gridDim.x >> 1)) ? 1 : 0)) : (wave >> 2);
+  int64_t ray = (int64_t)blockIdx.x * kRays + rs;
   const bool ray_ok = ray < a.n;
   if (!ray_ok) ray = a.n - 1;                        // keep the wave in the workgroup's lockstep
   float* ring = lds_dyn;
   float* act_ray = lds_dyn + kTRing + rs * (kShActSteps * 64);
-  float* scr = lds_dyn + kTRing + 2 * (kShActSteps * 64) + rs * kTScratch;
+  float* scr = lds_dyn + kTRing + kRays * (kShActSteps * 64) + rs * kTScratch;
   float* s_sd[2] = {scr, scr + 68};
   float* s_td = scr + 2 * 68; float* s_cw = scr + 3 * 68; float* s_c = scr + 4 * 68; float* s_v = scr + 5 * 68;
   float* s_out = scr + 6 * 68;
@@ -764,18 +774,18 @@ __global__ __launch_bounds__(kTW * 64, 2) void k_cache_fused_team(RcFusedArgs a)
 
 void rc_launch_fused_team(const RcFusedArgs& a, bool grad, hipStream_t stream) {
   static std::atomic<uint64_t> prepared{0};
-  const int lds = (kTRing + 2 * (kShActSteps * 64 + kTScratch)) * (int)sizeof(float);
-  static_assert((kTRing + 2 * (kShActSteps * 64 + kTScratch)) * sizeof(float) <= 80 * 1024, "two workgroups per CU");
+  const int lds = (kTRing + kRays * (kShActSteps * 64 + kTScratch)) * (int)sizeof(float);
+  static_assert((kTRing + kRays * (kShActSteps * 64 + kTScratch)) * sizeof(float) <= (kRays == 2 ? 80 : 160) * 1024, "two workgroups (one of eight waves) per CU");
   if (rc_first_use_on_device(prepared)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused_team<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cache_fused_team<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
-  dim3 grid((unsigned)((a.n + 1) / 2)), block(kTW * 64);
+  dim3 grid((unsigned)((a.n + kRays - 1) / kRays)), block(kTW * 64);
   RcFusedArgs b = a;
   // the priority scheme reads "second half of the grid" as "dispatched second onto its CU": true while the whole grid is
   // resident at once (two workgroups per CU); beyond that workgroups start as others finish and the scheme costs
   // 2.4 % (16 384 rays: 1790 -> 1833 us), so it is switched off
-  if ((int64_t)grid.x > 2 * (int64_t)rc_device_cus()) b.prio_mode = 0;
+  if ((int64_t)grid.x > 2 * (int64_t)rc_device_cus() || kRays != 2) b.prio_mode = 0;
   if (b.stagger_cycles > 0) {
     static std::atomic<int32_t*> slots{nullptr};       // one process drives one GPU (one handle per device)
     int32_t* p = slots.load();
