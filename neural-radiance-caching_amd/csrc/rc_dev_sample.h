@@ -158,17 +158,20 @@ template <bool BLOCK_SYNC = true>
 __device__ __forceinline__ void sample_intervals_wave(float logit, int P, int S, USpec us, bool has_jitter,
                                                       float jitter, const float* s_t, float* s_cw, float* s_c,
                                                       float* s_v, float* s_out, int lane) {
-  // softmax (jax.nn.softmax) + integrate_weights (stepfun.py:125-144)
-  const bool binact = lane < P;
-  const float m = wave_max(binact ? logit : -INFINITY);
-  const float e = binact ? expf(logit - m) : 0.0f;
-  const float ssum = wave_sum_scan(e);
-  const float wn = e / ssum;
-  const float incl = wave_scan_incl(wn, lane);
-  if (lane == 0) s_cw[0] = 0.0f;
-  if (lane < P - 1) s_cw[lane + 1] = fminf(1.0f, incl);
-  if (lane == 0) s_cw[P] = 1.0f;
-  lds_sync<BLOCK_SYNC>();
+  // softmax (jax.nn.softmax) + integrate_weights (stepfun.py:125-144).  One bin (the first level of every sampler call,
+  // wave-uniform): softmax of one logit is exp(0) / exp(0) = 1 and the CDF is [0, 1] whatever the logit -- no scans.
+  if (P > 1) {
+    const bool binact = lane < P;
+    const float m = wave_max(binact ? logit : -INFINITY);
+    const float e = binact ? expf(logit - m) : 0.0f;
+    const float ssum = wave_sum_scan(e);
+    const float wn = e / ssum;
+    const float incl = wave_scan_incl(wn, lane);
+    if (lane == 0) s_cw[0] = 0.0f;
+    if (lane < P - 1) s_cw[lane + 1] = fminf(1.0f, incl);
+    if (lane == 0) s_cw[P] = 1.0f;
+    lds_sync<BLOCK_SYNC>();
+  }
   // u (stepfun.py:186-202); linspace = start*(1-step) + stop*step, last == stop
   if (lane < S) {
     float u;
@@ -180,11 +183,20 @@ __device__ __forceinline__ void sample_intervals_wave(float logit, int P, int S,
     }
     if (has_jitter) u = u + jitter * us.max_jitter;
     // sorted_interp (math.py:448-457)
-    const int idx = upper_bound(s_cw, P + 1, u);
-    const int i1 = min(idx, P), i0 = max(idx - 1, 0);
-    const float c0 = s_cw[i0], c1 = s_cw[i1], t0 = s_t[i0], t1 = s_t[i1];
-    const float off = fminf(fmaxf((u - c0) / fmaxf(RC_EPS * RC_EPS, c1 - c0), 0.0f), 1.0f);
-    s_c[lane] = t0 + off * (t1 - t0);
+    if (P > 1) {
+      const int idx = upper_bound(s_cw, P + 1, u);
+      const int i1 = min(idx, P), i0 = max(idx - 1, 0);
+      const float c0 = s_cw[i0], c1 = s_cw[i1], t0 = s_t[i0], t1 = s_t[i1];
+      const float off = fminf(fmaxf((u - c0) / fmaxf(RC_EPS * RC_EPS, c1 - c0), 0.0f), 1.0f);
+      s_c[lane] = t0 + off * (t1 - t0);
+    } else {
+      // the same statements on cw = [0, 1]: searchsorted(side='right') gives 1 for u < 1 (interval [0, 1]) and 2 for
+      // u >= 1 (clamped to i0 = i1 = 1, offset clip(0 / eps^2) = 0) -- same operations on the same values, same bits
+      const bool in = u < 1.0f;
+      const float c0 = in ? 0.0f : 1.0f, t0 = in ? s_t[0] : s_t[1], t1 = s_t[1];
+      const float off = fminf(fmaxf((u - c0) / fmaxf(RC_EPS * RC_EPS, 1.0f - c0), 0.0f), 1.0f);
+      s_c[lane] = t0 + off * (t1 - t0);
+    }
   }
   lds_sync<BLOCK_SYNC>();
   // midpoints + reflected end posts, clip to [0,1] (stepfun.py:239-248)
