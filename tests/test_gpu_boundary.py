@@ -217,6 +217,13 @@ def test_render_image_distributed_over_rccl_with_one_rank():
         img, _ = M.render_image(M.bind_render_fn(M.create_render_fn(m)), None, rays, cfg, ("cache",), verbose=False)
         for k in ("rgb", "acc", "distance_median", "normals_pred"):
             assert np.array_equal(got[k].cpu().numpy(), img[k]), k
+        # to_host=True: numpy arrays out of ONE device-to-host copy of the gathered keys (pinned staging buffer, reused);
+        # two images in a row must not alias each other's arrays
+        host = M.render_image_distributed(apply, None, rays, cfg, keys=("rgb", "acc", "distance_median", "normals_pred"), to_host=True)
+        host2 = M.render_image_distributed(apply, None, rays, cfg, keys=("rgb", "acc"), to_host=True)
+        for k in ("rgb", "acc", "distance_median", "normals_pred"):
+            assert isinstance(host[k], np.ndarray) and np.array_equal(host[k], img[k]), k
+        assert np.array_equal(host2["rgb"], img["rgb"]) and not np.shares_memory(host2["rgb"], host["rgb"])
         key = prng.PRNGKey(3)
         rep = M.render_image_distributed(apply, key, rays, cfg, keys=("rgb", "acc"), num_repeats=3)
         one = M.render_image_distributed(apply, key, rays, cfg, keys=("rgb", "acc"), num_repeats=1)
