@@ -504,15 +504,18 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
 
   // Per-sample terms of this lane's 16 samples, kept in registers for all 66 tiles: weight, time shift, bin window
   float rw[16], rdm[16];
-  int rlo[16], rspan[16], rfl[16];
+  int rlo[16], rspan[16], rfl3[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
     rw[r] = sp[P_W * 32 + i];
     rdm[r] = sp[P_DIND * 32 + i];
-    rfl[r] = (int)floorf(rdm[r]);
-    rlo[r] = __float_as_int(sp[P_LO * 32 + i]);
-    rspan[r] = __float_as_int(sp[P_HI * 32 + i]) - rlo[r];          // < 0: empty window (unsigned compare below fails)
+    rfl3[r] = 3 * (int)floorf(rdm[r]);                               // entry offset of the time shift (3 entries per bin)
+    // window [lo, hi] as ONE unsigned compare in the epilogue: (unsigned)(b - lo) <= (unsigned)(hi - lo); an empty window
+    // (hi < lo) is stored as lo = 2^30, span = 0 -- no bin passes
+    const int lo_i = __float_as_int(sp[P_LO * 32 + i]), hi_i = __float_as_int(sp[P_HI * 32 + i]);
+    rlo[r] = hi_i >= lo_i ? lo_i : (1 << 30);
+    rspan[r] = hi_i >= lo_i ? hi_i - lo_i : 0;
   }
   // value of the tile before, per sample (see the epilogue)
   float cval[16];
@@ -540,6 +543,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
       const bool fok = f < kHist;
       const int b = f / 3, c = f - 3 * b;
       const float b_f = (float)b, bm1_f = (float)(b - 1);
+      const int b_live = fok ? b : -(1 << 29);     // an entry beyond the histogram passes no sample's window test
+      // this lane's column of the per-sample tint table, kept in a register for the tile's 16 samples (left to itself the
+      // compiler re-derives it with a 64-bit multiply-add per sample)
+      const float* tibp = sp + (P_TIB0 + c) * 32 + 4 * h;
+      asm volatile("" : "+v"(tibp));
       float cd = 0.0f, cs = 0.0f;                  // unshifted composites over this half-wave's 16 samples
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -549,9 +557,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
 #endif
         // A sample whose window misses every bin of this tile contributes exact zeros: skip it for the whole wave
         // (unless the tile before left it a value to place, see below).
-        const bool live = fok && rspan[r] >= 0 && (unsigned)(b - rlo[r]) <= (unsigned)rspan[r];
-        const bool carry_in = fl >= 29 && cval[r] != 0.0f;
-        if (__ballot(live || carry_in) == 0ull) continue;
+        const bool live = (unsigned)(b_live - rlo[r]) <= (unsigned)rspan[r];
+        const bool carry_in = (fl >= 29) & (cval[r] != 0.0f);
+        if (__builtin_amdgcn_ballot_w64(live | carry_in) == 0ull) continue;
         const float w = rw[r];
         // shift_map_coordinates (render.py:480-496): out[y] = in(y - d), linear, zero outside.  Entry b of this sample
         // reaches y0 = b + floor(d) and y0 + 1, and y0 also receives the second part of entry b - 1 -- the lane three
@@ -561,13 +569,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
         // below cover its latency.  The lanes of the first three entries take the neighbour's value from the tile
         // before (cval); a target outside the histogram goes to the lane's dummy slot.
         const float dmove = rdm[r];
-        const int y0 = b + rfl[r];
-        const bool yok = (unsigned)y0 < (unsigned)kBins;
-        float* slot = hist_h + (yok ? y0 * 3 + c : kHist + fl);
+        // target entry 3 y0 + c = f + 3 floor(d); inside the histogram exactly when 0 <= y0 < kBins (c < 3)
+        const int e0 = f + rfl3[r];
+        const bool yok = (unsigned)e0 < (unsigned)kHist;
+        float* slot = hist_h + (yok ? e0 : kHist + fl);
 #if !(defined(RC_ABL) && RC_ABL == 2)
         const float old = *slot;
 #endif
-        const float tib = sp[(P_TIB0 + c) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+        const float tib = tibp[(r & 3) + 8 * (r >> 2)];
         // nerf.py:1795-1797 and :1712-1719: softplus(. + irradiance_bias) * indirect_scale;
         // surface_light_field.py:1037-1058 and nerf.py:1721-1723: tint * ibrdf * clip(softplus(. + rgb_bias), 0) * scale
 #if defined(RC_ABL) && RC_ABL == 3
@@ -576,6 +585,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
 #else
         float diff = softplus_bins(ai[r] + a.irradiance_bias) * a.indirect_scale;
         const float ref = fmaxf(softplus_bins(1.0f * as[r] + a.slf_rgb_bias), 0.0f);
+        // keep the value in front of the `live` select below: the optimizer otherwise sinks this chain into a divergent
+        // branch on `live` (s_and_saveexec / s_cbranch / s_or exec per iteration) where one v_cndmask does
+        asm volatile("" : "+v"(diff));
 #endif
         float spec = (tib * ref) * a.indirect_scale;
         // jnp.clip(x, 0, rgb_max) (nerf.py:1757-1758) as ONE v_med3_f32: the median of (x, 0, rgb_max) is the clamp for
@@ -596,7 +608,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
         // i0 is b - 1 (wa = fw, wb = 1 - fw) or, when d is integral or t rounds up to b, b (wa = 1 - fw, wb = 0);
         // the reference's other terms are exact zeros.
         // (t in [b - 1, b]: floor(t) is b exactly when t == b, else b - 1; both are constants of the lane for the tile)
-        const float t = (float)y0 - dmove;
+        const float t = (b_f + floorf(dmove)) - dmove;        // (float)y0, y0 = b + floor(d): both are small integers, the sum is exact
         const bool at_b = t == b_f;
         const float fw = at_b ? 0.0f : t - bm1_f;
         const float wa = at_b ? 1.0f : fw;
