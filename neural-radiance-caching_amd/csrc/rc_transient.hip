@@ -546,8 +546,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
       const int b_live = fok ? b : -(1 << 29);     // an entry beyond the histogram passes no sample's window test
       // this lane's column of the per-sample tint table, kept in a register for the tile's 16 samples (left to itself the
       // compiler re-derives it with a 64-bit multiply-add per sample)
-      const float* tibp = sp + (P_TIB0 + c) * 32 + 4 * h;
-      asm volatile("" : "+v"(tibp));
+      int tib_off = (P_TIB0 + c) * 32 + 4 * h;     // (the OFFSET is pinned, not a pointer: a pinned pointer loses its LDS address space)
+      asm volatile("" : "+v"(tib_off));
       float cd = 0.0f, cs = 0.0f;                  // unshifted composites over this half-wave's 16 samples
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
         // A sample whose window misses every bin of this tile contributes exact zeros: skip it for the whole wave
         // (unless the tile before left it a value to place, see below).
         const bool live = (unsigned)(b_live - rlo[r]) <= (unsigned)rspan[r];
-        const bool carry_in = (fl >= 29) & (cval[r] != 0.0f);
+        const bool carry_in = cval[r] != 0.0f;       // cval is kept on the lanes that serve the next tile only (fl >= 29)
         if (__builtin_amdgcn_ballot_w64(live | carry_in) == 0ull) continue;
         const float w = rw[r];
         // shift_map_coordinates (render.py:480-496): out[y] = in(y - d), linear, zero outside.  Entry b of this sample
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
 #if !(defined(RC_ABL) && RC_ABL == 2)
         const float old = *slot;
 #endif
-        const float tib = tibp[(r & 3) + 8 * (r >> 2)];
+        const float tib = sp[tib_off + (r & 3) + 8 * (r >> 2)];
         // nerf.py:1795-1797 and :1712-1719: softplus(. + irradiance_bias) * indirect_scale;
         // surface_light_field.py:1037-1058 and nerf.py:1721-1723: tint * ibrdf * clip(softplus(. + rgb_bias), 0) * scale
 #if defined(RC_ABL) && RC_ABL == 3
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
         // bpermute: the lanes that serve the second case (fl >= 29) are never a source of the first
         const float nb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(
             nb_addr, __builtin_bit_cast(int, fl >= 29 ? cval[r] : val)));
-        cval[r] = val;
+        cval[r] = fl >= 29 ? val : 0.0f;
         // The weights are those the target bin computes (coordinate t = y0 - d, i0 = floor(t), fw = t - i0; weight
         // 1 - fw to source bin i0 and fw to i0 + 1): wa for source b, wb for source b - 1.  t lies in [b - 1, b], so
         // i0 is b - 1 (wa = fw, wb = 1 - fw) or, when d is integral or t rounds up to b, b (wa = 1 - fw, wb = 0);
