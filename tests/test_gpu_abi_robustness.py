@@ -346,3 +346,48 @@ def test_material_stage_with_per_stage_profiling_on_takes_the_envmap_along():
     for k in res[0]:
         assert torch.equal(res[0][k], res[1][k]) and torch.equal(res[0][k], res[2][k]), k
     assert any(float(v.abs().sum()) > 0 for k, v in res[0].items() if k.startswith("m:"))
+
+
+def test_f4_density_records_can_be_left_out(tmp_path):
+    """RC_REC4_TABLES=0 (read once per process, hence the child process): the handle is built without the 2.5 GB of cell
+    records of the F = 4 density grid and the level kernels of the secondary trace read the hash tables instead -- every
+    output of the material stage is bitwise what the handle with the records renders."""
+    import os
+    import subprocess
+    import sys
+    from oracle import material_ref
+    from nrc_amd import rc_ext
+    n = 130
+    cfg = nrc_amd.hotdog_config()
+    rc = rc_ext.RadianceCache(cfg, 0)
+    rc.load_weights(common.weights_material_np(False))
+    rays = nrc_amd.synthetic_rays(n, seed=5)
+    rnd = material_ref.draw_randoms(cfg, n, seed=8)
+    cres, mres = rc.render_material(rays.hot_fields(), rnd)
+    torch.cuda.synchronize()
+    want = {"c:" + k: v.cpu().numpy() for k, v in cres.items()}
+    want.update({"m:" + k: v.cpu().numpy() for k, v in mres.items()})
+    out = tmp_path / "norec.npz"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = f"""
+import sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+import numpy as np, torch
+import common, nrc_amd
+from nrc_amd import rc_ext
+from oracle import material_ref
+cfg = nrc_amd.hotdog_config()
+rc = rc_ext.RadianceCache(cfg, 0)
+rc.load_weights(common.weights_material_np(False))
+rays = nrc_amd.synthetic_rays({n}, seed=5)
+cres, mres = rc.render_material(rays.hot_fields(), material_ref.draw_randoms(cfg, {n}, seed=8))
+torch.cuda.synchronize()
+got = {{"c:" + k: v.cpu().numpy() for k, v in cres.items()}}
+got.update({{"m:" + k: v.cpu().numpy() for k, v in mres.items()}})
+np.savez({str(out)!r}, **got)
+"""
+    subprocess.run([sys.executable, "-c", child], check=True, env=dict(os.environ, RC_REC4_TABLES="0"), timeout=600)
+    got = np.load(out)
+    assert set(got.files) == set(want)
+    for k, v in want.items():
+        assert np.array_equal(got[k], v, equal_nan=True), k
