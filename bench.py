@@ -13,8 +13,8 @@ as the image renderer does once per image.
 
 The timed loop cycles through 64 different resident ray batches (no step re-renders the rays of the step before).
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_cache_fused, fp32 MFMA
-bound); its duration comes from HIP events recorded on the launch stream inside the timed region; `traffic` is read
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused cache kernel, MFMA bound: priced in
+algorithmic fp32 flops against the fp32 MFMA peak, `roofline.issued_bf16` the split build's products on the bf16 pipe); its duration comes from HIP events recorded on the launch stream inside the timed region; `traffic` is read
 from the PMC file tools/prof_round.sh leaves under profiles/ and is null when that file belongs to other kernel sources.
 `hashgrid` reports the achieved algorithmic GB/s of the grid lookups twice: of the four stand-alone kernels (measured
 here, separate pass on the launch-per-stage plan) and of the gather phases inside the fused kernel (in-kernel stamps
@@ -380,6 +380,11 @@ def main():
     fused = args.plan in ("fused", "fused1")
     fused_mode = {"fused": 1, "fused1": 3, "staged": 0}[args.plan]
     rc.set_fused(fused_mode)
+    # how the library multiplies in the shader MLPs (include/rc_abi.h rc_mlp_arithmetic).  A bf16x3-split build runs the
+    # one-wave-per-ray kernel for the default plan too: the two-wave kernel puts two waves on a SIMD
+    arith = rc_ext.mlp_arithmetic()
+    dominant = {"fused": "k_cache_fused" if arith == "bf16x3-split" else "k_cache_fused_team", "fused1": "k_cache_fused",
+                "staged": "k_cache_shader"}[args.plan]
 
     def batch(seed):
         r = nrc_amd.synthetic_rays(RAYS_PER_BATCH, seed=seed)
@@ -507,12 +512,24 @@ def main():
                    "launch": "eager" if (args.profile_mode or args.graph_mode == 0 or fused) else "hipGraph",
                    "batches_in_flight": nstr,
                    "ms_per_step_runs": [e / args.steps * 1e3 for e in run_s],
-                   "kernel_plan": {"fused": "fused: 1 launch per batch, 2 wavefronts per ray, 2 workgroups per CU (k_cache_fused_team)",
+                   "kernel_plan": {"fused": ("fused: 1 launch per batch, 1 wavefront per ray (k_cache_fused)" if arith == "bf16x3-split" else
+                                             "fused: 1 launch per batch, 2 wavefronts per ray, 2 workgroups per CU (k_cache_fused_team)"),
                                    "fused1": "fused: 1 launch per batch, 1 wavefront per ray (k_cache_fused)",
                                    "staged": "staged: 13 launches per batch"}[args.plan],
+                   "mlp_arithmetic": ("shader MLPs: fp32 operands split exactly into 3 bf16 pieces, 6 products per fp32 product on "
+                                      "v_mfma_f32_32x32x16_bf16, fp32 accumulation (fp32-grade: the noise-floor parity test); "
+                                      "density MLPs: v_mfma_f32_32x32x2_f32" if arith == "bf16x3-split" else
+                                      "every MLP layer on v_mfma_f32_32x32x2_f32 (exact fp32 chain)"),
                    "kernel_source_hash": src_hash},
-        "roofline": {"kernel": {"fused": "k_cache_fused_team", "fused1": "k_cache_fused", "staged": "k_cache_shader"}[args.plan], "bound": "mfma", "achieved": achieved_tf,
+        "roofline": {"kernel": dominant, "bound": "mfma", "achieved": achieved_tf,
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
+                     # `achieved` counts the ALGORITHMIC fp32 flops; `peak` stays the fp32 MFMA peak -- the precision the
+                     # path delivers and the unit earlier rounds were priced in.  A split build issues the shader's share
+                     # (8.32 of the 9.94 GFLOP) six times over on the bf16 pipe (2500 TF dense): `issued_bf16` prices that
+                     "issued_bf16": (None if arith != "bf16x3-split" else
+                                     {"flop_per_launch": 6 * 253824 * 32 * RAYS_PER_BATCH,
+                                      "achieved": 6 * 253824 * 32 * RAYS_PER_BATCH / (sh_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                                      "frac": 6 * 253824 * 32 * RAYS_PER_BATCH / (sh_ms * 1e-3) / 1e12 / 2500.0}),
                      # HBM-side bytes per launch: FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes (KiB as
                      # reported: random 4/16-byte gathers, the x2 correction for wide streaming reads does not apply);
                      # null when the file under profiles/ was not measured on these kernel sources

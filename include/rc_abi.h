@@ -216,6 +216,11 @@ int rc_create(const rc_config* cfg, int device, rc_handle** out);
 void rc_destroy(rc_handle* h);
 const char* rc_last_error(const rc_handle* h);   /* h may be NULL: last error of rc_create */
 int rc_abi_version(void);
+/* Arithmetic of the shader / EnvMap MLP layers this library was built with (csrc/rc_pack_host.h RC_SPLIT_MFMA):
+ * 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, the exact fp32 chain); 1 = every fp32 operand split exactly into three bf16
+ * pieces, six products per 16 k on v_mfma_f32_32x32x16_bf16, fp32 accumulation (same error against fp64 as the fp32 chain:
+ * tests/test_gpu_parity.py, the noise-floor test).  The density MLPs of the proposal levels are fp32 MFMA in both. */
+int rc_mlp_arithmetic(void);
 
 /* -- weights: replaces flax `variables` passed to model.apply (internal/train_utils.py:3796-3814)
  * May be called several times; tensors with unknown names are rejected.

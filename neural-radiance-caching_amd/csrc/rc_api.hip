@@ -467,12 +467,13 @@ int repack(rc_handle* h) {
     if (!missing.empty()) return fail(h, RC_ERR_MISSING_WEIGHT, "missing weight: " + missing);
     std::vector<Step> s;
     steps_natural(s, d0->in, 0); step_bias(s);
-    std::vector<float> stream = pack(s, {tile_full(d0, 0), tile_full(d0, 1)});
+    // density MLPs: fp32 fragments in every build (rc_pack_host.h rc_lfr32, rc_dev_mlp.h mlp_layer_d)
+    std::vector<float> stream = pack_f32(s, {tile_full(d0, 0), tile_full(d0, 1)});
     s.clear(); steps_acc(s, 2, 0); step_bias(s);
-    append(stream, pack(s, {tile_full(d1, 0), tile_full(d1, 1)}));
+    append(stream, pack_f32(s, {tile_full(d1, 0), tile_full(d1, 1)}));
     std::vector<Col> regs = {Col{dout, 0}};
     if (dn) { regs.push_back(Col{dn, 0}); regs.push_back(Col{dn, 1}); regs.push_back(Col{dn, 2}); }
-    append(stream, pack_dot(regs, 2));
+    append(stream, pack_dot(regs, 2, false));
     if (dn) {
       // backward fragments for the analytic normals (last level): W1^T, W0^T (w_out is kept from the forward dot)
       HostLayer w1t, w0t;
@@ -481,8 +482,8 @@ int repack(rc_handle* h) {
       w0t.in = d0->out; w0t.out = d0->in; w0t.kernel.resize(d0->kernel.size()); w0t.bias.assign(w0t.out, 0.0f);
       for (int r = 0; r < d0->in; ++r) for (int c2 = 0; c2 < d0->out; ++c2) w0t.kernel[(size_t)c2 * w0t.out + r] = d0->kernel[(size_t)r * d0->out + c2];
       std::vector<Step> sb; steps_acc(sb, 2, 0);
-      append(stream, pack(sb, {tile_full(&w1t, 0, 0, false), tile_full(&w1t, 1, 0, false)}));
-      append(stream, pack(sb, {tile_full(&w0t, 0, 0, false)}));
+      append(stream, pack_f32(sb, {tile_full(&w1t, 0, 0, false), tile_full(&w1t, 1, 0, false)}));
+      append(stream, pack_f32(sb, {tile_full(&w0t, 0, 0, false)}));
     }
     if (l < 3) fused_parts[l] = stream;
     int rc = upload(h, "dens_" + std::to_string(l), pad_stream(stream));
@@ -498,6 +499,7 @@ int repack(rc_handle* h) {
       ok = (int)(stream.size() / 64) == off[p];
       append(stream, fused_parts[p]);
     }
+    if (ok && (int)(stream.size() / 64) < off[3] && off[3] - (int)(stream.size() / 64) < 4) stream.resize((size_t)off[3] * 64, 0.0f);
     ok = ok && (int)(stream.size() / 64) == off[3];
     h->fused_front_ok = ok;
     if (ok) {
@@ -571,6 +573,7 @@ int repack(rc_handle* h) {
     bool ok = fused_geometry_ok(h);
     std::vector<float> stream;
     for (int p = 0; p < 4 && ok; ++p) {
+      if (p == 3 && (int)(stream.size() / 64) < off[p] && off[p] - (int)(stream.size() / 64) < 4) stream.resize((size_t)off[p] * 64, 0.0f);   // split layers start on a whole piece (F_SH)
       ok = (int)(stream.size() / 64) == off[p];
       append(stream, fused_parts[p]);
     }
@@ -809,6 +812,7 @@ __global__ void k_env_combine(int64_t n, const float* rgb_noenv, const float* ac
 extern "C" {
 
 int rc_abi_version(void) { return RC_ABI_VERSION; }
+int rc_mlp_arithmetic(void) { return kRcSplit ? 1 : 0; }
 int rc_stage_count(void) { return ST_COUNT; }
 const char* rc_stage_name(int32_t s) { return (s >= 0 && s < ST_COUNT) ? kStageNames[s] : ""; }
 
@@ -1106,7 +1110,12 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     for (int l = 0; l < 3; ++l) F.jitter[l] = rnd ? rnd->jitter[l] : nullptr;
     F.out = A.out;
     F.direct = h->fused_direct;
-    F.team = h->fused_mode == 1 ? 1 : 0;          // mode 3: the one-wavefront-per-ray form
+    // mode 3: the one-wavefront-per-ray form.  Builds with the split-MFMA shader (RC_SPLIT_MFMA) run it for mode 1 as well:
+    // the two-wave kernel puts two waves on a SIMD, where the split form hit an operand hazard (rc_dev_mlp.h HAZARD)
+    // (RC_TEAM_SPLIT=1 in the environment puts the two-wave kernel back under the split form: the configuration
+    // tools/stress_repeat.py shows the hazard on -- for diagnosis only, its results are wrong in one ray of a few hundred)
+    static const bool team_split = getenv("RC_TEAM_SPLIT") && getenv("RC_TEAM_SPLIT")[0] == '1';
+    F.team = (h->fused_mode == 1 && (!kRcSplit || team_split)) ? 1 : 0;
     F.stagger_cycles = h->fused_stagger;
     F.prio_mode = h->fused_prio;
     if (A.export_samples) {

@@ -448,7 +448,14 @@ __device__ __forceinline__ void grid_level(const RcGridLevel& L, float bbox, flo
   // power-of-two table or not decided ONCE per level (wave-uniform): as a test per corner the modulo path put eight
   // branches and ~160 instructions between the index arithmetic and the first load (r04_bisect_hashgrid_standalone.txt)
   const float x01 = unit_box(bbox, x), y01 = unit_box(bbox, y), z01 = unit_box(bbox, z);
-  if (L.dense != 0 || L.mask != 0u) grid_fetch<F, true, 1, false, true>(L.table, L.size, L.mask, L.entries, L.dense != 0, x01, y01, z01, C);
+  if (L.rec != nullptr) {
+    // a hashed level with cell records (wave-uniform): the lanes whose point lies inside the bounding box read their 8
+    // corners as ONE record (32 bytes at F = 1, one 128-byte line at F = 4) instead of ~4 sectors of the hash table; a
+    // point outside it has no record of its own (hrec_index clamps) and takes the hash table -- this kernel's features are
+    // an output (rc_hashgrid_lookup), so they must be right out there too.  Same entries, weights and corner order.
+    const bool in01 = (x01 >= 0.0f) & (x01 <= 1.0f) & (y01 >= 0.0f) & (y01 <= 1.0f) & (z01 >= 0.0f) & (z01 <= 1.0f);
+    grid_fetch<F, true, 1, false, true>(in01 ? L.rec : L.table, L.size, L.mask, L.entries, false, x01, y01, z01, C, in01);
+  } else if (L.dense != 0 || L.mask != 0u) grid_fetch<F, true, 1, false, true>(L.table, L.size, L.mask, L.entries, L.dense != 0, x01, y01, z01, C);
   else grid_fetch<F, false, 1, false, true>(L.table, L.size, L.mask, L.entries, false, x01, y01, z01, C);
   grid_combine<F, JAC, false>(C, acc, jacc);
 }

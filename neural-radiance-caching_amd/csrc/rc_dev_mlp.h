@@ -17,6 +17,77 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split arithmetic (rc_pack_host.h, RC_SPLIT_MFMA): fp32 operands as three bf16 pieces each, six products per 16 k on
+// v_mfma_f32_32x32x16_bf16.  The weights are split by the host; the activations here, once per block of 8 k-steps (the 8
+// values a lane holds: its own column, its own half-wave -- the k-slots of the MFMA's B operand, which pair with the
+// A operand's slots positionally, so the step order of the fp32 form stays as it is).
+// ---------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// bf16 (truncated) of a0 in the low half, of a1 in the high half
+__device__ __forceinline__ uint32_t pack_top16(float a1, float a0) {
+  return __builtin_amdgcn_perm(__float_as_uint(a1), __float_as_uint(a0), 0x07060302u);
+}
+__device__ __forceinline__ float top16(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
+// v[j] == hi[j] + mid[j] + lo[j] exactly (each residual is exact: the top shares its leading bits)
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&b)[3]) {
+  u32x4 &hi = b[0], &mid = b[1], &lo = b[2];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float a0 = v[2 * p], a1 = v[2 * p + 1];
+    hi[p] = pack_top16(a1, a0);
+    const float r0 = a0 - top16(a0), r1 = a1 - top16(a1);
+    mid[p] = pack_top16(r1, r0);
+    const float l0 = r0 - top16(r0), l1 = r1 - top16(r1);
+    lo[p] = pack_top16(l1, l0);
+  }
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// HAZARD (measured, ROCm 7.2 / gfx950; tools/stress_repeat.py, profiles/r04_split_mfma_hazard.txt): with two or more
+// waves per SIMD a v_mfma_f32_32x32x16_bf16 does not always fetch its A / B operands at issue -- while the matrix pipe
+// runs another wave's MFMA it stays pending and fetches them when it starts.  An instruction of the same wave that
+// overwrites an operand register in between changes the product (the compiler reuses the registers of a cell's pieces
+// for the next block's split a few instructions behind the MFMA: it knows no such hazard, and its wait states for the
+// accumulators count from the ISSUE of the last MFMA).  Seen as one ray in a few hundred off by ~1e-3 in some launches,
+// never with one wave per SIMD, never with the 16-pass fp32 MFMA (it holds the SIMD's vector issue while it runs).
+// The rules below need no timing assumption, only that a wave's MFMA issues once its previous one has started and that
+// the matrix pipe runs a wave's MFMAs in order:
+//  1. the MFMAs of a cell issue back to back (scheduling barriers), nothing of the wave in between;
+//  2. the operand registers of a cell stay live (split_keep: an empty asm that reads them) until the MFMAs of the NEXT
+//     cell have issued -- by then every MFMA of the cell has started; weight pieces rotate through three register sets,
+//     activation pieces through two, loads and splits into a set follow the marker that retires it;
+//  3. behind a layer's last cell two flush MFMAs (16x16x32 into a 4-register sink that lives as long as the stream
+//     object and is never read) issue before the accumulators are read or the last operands are released: the second
+//     issues once the first has started, i.e. once every MFMA of the layer has finished.  A flush fetching stale
+//     operands or completing late only touches the sink.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_keep(const u32x4& x) { asm volatile("" ::"v"(x)); }
+__device__ __forceinline__ void split_keep3(const u32x4 (&x)[3]) { asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(x[2])); }
+template <class WS>
+__device__ __forceinline__ void split_flush(const WS& w, const u32x4& any) {
+  __builtin_amdgcn_sched_barrier(0);
+  w.sink = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, any), __builtin_bit_cast(bf16x8, any), w.sink, 0, 0, 0);
+  w.sink = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, any), __builtin_bit_cast(bf16x8, any), w.sink, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 1" : "+v"(w.sink));
+  __builtin_amdgcn_sched_barrier(0);
+}
+// the six products of one (block, tile) cell, smallest first
+__device__ __forceinline__ void mfma_split6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16& acc) {
+  __builtin_amdgcn_sched_barrier(0);
+  acc = mfma_bf16(a[2], b[0], acc);
+  acc = mfma_bf16(a[0], b[2], acc);
+  acc = mfma_bf16(a[1], b[1], acc);
+  acc = mfma_bf16(a[1], b[0], acc);
+  acc = mfma_bf16(a[0], b[1], acc);
+  acc = mfma_bf16(a[0], b[0], acc);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Weight stream.  All MLP layers of a kernel are packed by the host into ONE linear stream of
 // 256-byte MFMA A-fragments in exactly the order the kernel consumes them.  The workgroup pulls
 // the stream through a two-chunk LDS ring with LDS-DMA (global_load_lds_dwordx4, no VGPRs): while
@@ -33,6 +104,9 @@ struct WStream {
   const float* g;    // packed fragment stream (padded to a whole number of chunks)
   float* ring;       // LDS ring [2 * kChunk][64]
   int lane, wave;
+  mutable f32x4 sink = {0.0f, 0.0f, 0.0f, 0.0f};     // split form: destination of the flush MFMAs (see HAZARD above), never read
+  __device__ WStream() = default;
+  __device__ WStream(const float* g_, float* ring_, int lane_, int wave_) : g(g_), ring(ring_), lane(lane_), wave(wave_) {}
 };
 
 // Issue the LDS-DMA of chunk c (this wave's quarter: 4 x 1 KiB).
@@ -65,6 +139,7 @@ template <int NF, int W = kWaves, int CH = kChunk>
 __device__ __forceinline__ void ws_advance(const WStream& w, int c) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+
   if ((c + 1) * CH < NF) ws_issue<NF, W, CH>(w, c + 1);
 }
 
@@ -75,6 +150,15 @@ __device__ __forceinline__ float ws_read(const WStream& w, int f) {
   return w.ring[(f % (2 * CH)) * 64 + w.lane];
 }
 
+// One 1-KiB piece of the split form (fragments [f, f + 4), f a multiple of 4): this lane's 8 bf16.
+__device__ __forceinline__ u32x4 lds_piece(const float* p) { return *reinterpret_cast<const u32x4*>(p); }
+template <int NF, int W = kWaves, int CH = kChunk>
+__device__ __forceinline__ u32x4 ws_read4(const WStream& w, int f) {
+  static_assert(CH % 4 == 0, "pieces never straddle a chunk");
+  if (f > 0 && f % CH == 0) ws_advance<NF, W, CH>(w, f / CH);
+  return lds_piece(w.ring + (f % (2 * CH)) * 64 + w.lane * 4);
+}
+
 // The same fragment stream read straight from global memory (L2-resident: one kernel's stream is <= 0.7 MB), one
 // coalesced 256-byte load per fragment and wave, no LDS ring and therefore NO workgroup barriers: the waves of a
 // workgroup are free to drift apart.  Which stream type a kernel uses is a property of the kernel; the arithmetic
@@ -82,17 +166,20 @@ __device__ __forceinline__ float ws_read(const WStream& w, int f) {
 struct WDirect {
   const float* g;
   int lane;
+  mutable f32x4 sink = {0.0f, 0.0f, 0.0f, 0.0f};
 };
 template <int NF, int W = kWaves, int CH = kChunk>
 __device__ __forceinline__ float ws_read(const WDirect& w, int f) { return w.g[(size_t)f * 64 + w.lane]; }
+template <int NF, int W = kWaves, int CH = kChunk>
+__device__ __forceinline__ u32x4 ws_read4(const WDirect& w, int f) { return *reinterpret_cast<const u32x4*>(w.g + (size_t)f * 64 + w.lane * 4); }
 
 // One pass over KS k-steps for NT output tiles; the layer's fragments are [FBASE, FBASE + KS*NT)
 // of the stream.  act: this lane's activation column (act[s * 64] is step s).
 // Software pipelined in groups of SG k-steps: the LDS reads (A fragments + B activations) of group
 // g+1 are issued before the MFMAs of group g, with scheduling fences so they stay there; the MFMA
 // pipe then runs back to back while the next operands are in flight.
-template <int NT, int KS, int FBASE, int NF, int SG = (NT >= 8 ? 1 : (NT >= 4 ? 2 : (NT >= 2 ? 4 : 8))), int W = kWaves, int CH = kChunk, class WS = WStream>
-__device__ __forceinline__ void mlp_layer(const WS& w, const float* act, f32x16 (&acc)[NT]) {
+template <int NT, int KS, int FBASE, int NF, int SG, int W, int CH, class WS>
+__device__ __forceinline__ void mlp_layer_f32(const WS& w, const float* act, f32x16 (&acc)[NT]) {
   constexpr int NG = (KS + SG - 1) / SG;
   float a[3][SG][NT], b[3][SG];
   auto load = [&](int g, int buf) {
@@ -134,11 +221,91 @@ __device__ __forceinline__ void mlp_layer(const WS& w, const float* act, f32x16 
 }
 
 
+// The split form of the same pass: blocks of 8 k-steps, cells (block, tile) of three 1-KiB pieces in stream order.  The
+// activations of the next block and the pieces of the next cell are read before the six MFMAs of the current one.
+template <int NT, int KS, int FBASE, int NF, int W, int CH, class WS>
+__device__ __forceinline__ void mlp_layer_split(const WS& w, const float* act, f32x16 (&acc)[NT]) {
+  static_assert(FBASE % 4 == 0, "split layers start on a 1-KiB piece");
+  constexpr int NB = (KS + 7) / 8, NC = NB * NT;
+  float bv[8];
+  u32x4 a[3][3], b[2][3];
+  auto load_b = [&](int q) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = (8 * q + j < KS) ? act[(8 * q + j) * 64] : 0.0f;
+  };
+  auto load_a = [&](int cell) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) a[cell % 3][p] = ws_read4<NF, W, CH>(w, FBASE + (cell * 3 + p) * 4);
+  };
+  load_b(0);
+  load_a(0);
+  if (NC > 1) load_a(1);
+  split8(bv, b[0]);
+  if (NB > 1) load_b(1);
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int cell = q * NT + t;
+      mfma_split6(a[cell % 3], b[q & 1], acc[t]);
+      // the MFMAs of this cell have issued: those of the cell before have started, its registers may go
+      if (cell >= 1) split_keep3(a[(cell - 1) % 3]);
+      if (cell + 2 < NC) load_a(cell + 2);
+      if (t == 0) {
+        if (q >= 1) split_keep3(b[(q - 1) & 1]);
+        if (q + 1 < NB) {
+          split8(bv, b[(q + 1) & 1]);
+          if (q + 2 < NB) load_b(q + 2);
+        }
+      }
+    }
+  }
+  split_flush(w, b[(NB - 1) & 1][0]);
+  split_keep3(a[(NC - 1) % 3]);
+  split_keep3(b[(NB - 1) & 1]);
+}
+
+template <int NT, int KS, int FBASE, int NF, int SG = (NT >= 8 ? 1 : (NT >= 4 ? 2 : (NT >= 2 ? 4 : 8))), int W = kWaves, int CH = kChunk, class WS = WStream>
+__device__ __forceinline__ void mlp_layer(const WS& w, const float* act, f32x16 (&acc)[NT]) {
+  if constexpr (kRcSplit) mlp_layer_split<NT, KS, FBASE, NF, W, CH, WS>(w, act, acc);
+  else mlp_layer_f32<NT, KS, FBASE, NF, SG, W, CH, WS>(w, act, acc);
+}
+
+// A layer of a proposal level's density MLP: the exact fp32 MFMA chain in every build (rc_pack_host.h rc_lfr32).
+template <int NT, int KS, int FBASE, int NF, int SG = (NT >= 8 ? 1 : (NT >= 4 ? 2 : (NT >= 2 ? 4 : 8))), int W = kWaves, int CH = kChunk, class WS = WStream>
+__device__ __forceinline__ void mlp_layer_d(const WS& w, const float* act, f32x16 (&acc)[NT]) {
+  mlp_layer_f32<NT, KS, FBASE, NF, SG, W, CH, WS>(w, act, acc);
+}
+
 // The bias k-step of a layer (fragments [FBASE, FBASE + NT): the bias row of each tile) with its B operand -- 1 on the
 // first half-wave, 0 on the second -- taken from a register instead of an activation slot: a 256-wide layer then needs
 // 128 activation steps in LDS, not 129.  Same MFMAs in the same order as a 129th step of mlp_layer.
 template <int NT, int FBASE, int NF, int W = kWaves, int CH = kChunk, class WS = WStream>
 __device__ __forceinline__ void mlp_bias_step(const WS& w, f32x16 (&acc)[NT]) {
+  if constexpr (kRcSplit) {
+    // the layer's last block, whose only live step is the bias step (slot 0 of the first half-wave): B = bf16(1) there,
+    // so the three pieces of the bias row add up exactly (hi + mid + lo) in three MFMAs per tile
+    u32x4 b1;
+    b1[0] = w.lane < 32 ? 0x00003f80u : 0u; b1[1] = 0u; b1[2] = 0u; b1[3] = 0u;
+    u32x4 a[NT][3];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[t][p] = ws_read4<NF, W, CH>(w, FBASE + (t * 3 + p) * 4);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      __builtin_amdgcn_sched_barrier(0);
+      acc[t] = mfma_bf16(a[t][2], b1, acc[t]);
+      acc[t] = mfma_bf16(a[t][1], b1, acc[t]);
+      acc[t] = mfma_bf16(a[t][0], b1, acc[t]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    split_flush(w, b1);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) split_keep3(a[t]);
+    split_keep(b1);
+    return;
+  }
   const float one = w.lane < 32 ? 1.0f : 0.0f;
   float a[NT];
 #pragma unroll
@@ -147,8 +314,8 @@ __device__ __forceinline__ void mlp_bias_step(const WS& w, f32x16 (&acc)[NT]) {
   for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], one, acc[t], 0, 0, 0);
 }
 
-// Same as mlp_layer for PT point-tiles per wave (64 points): every A fragment read from the ring feeds
-// PT MFMAs.  Tile p's activation column starts at act + p * tile_stride.
+// Same as mlp_layer_d (density MLPs: fp32 MFMA in every build) for PT point-tiles per wave (64 points): every A fragment
+// read from the ring feeds PT MFMAs.  Tile p's activation column starts at act + p * tile_stride.
 template <int PT, int NT, int KS, int FBASE, int NF, int SG = (NT * PT >= 8 ? 1 : (NT * PT >= 4 ? 2 : 4)), int W = kWaves, class WS = WStream>
 __device__ __forceinline__ void mlp_layer_pt(const WS& w, const float* act, int tile_stride, f32x16 (&acc)[PT][NT]) {
   constexpr int NG = (KS + SG - 1) / SG;
@@ -193,7 +360,15 @@ __device__ __forceinline__ void mlp_layer_pt(const WS& w, const float* act, int 
 
 // max(x, 0) as ONE instruction.  fmaxf() on a value the compiler cannot prove canonical -- an MFMA result -- is preceded
 // by a canonicalising `v_max_f32 x, x, x`: two instructions per activation, 64 per 32-point tile of a proposal MLP.
+// Split form: the inline-asm read of an accumulator right behind a v_mfma_f32_32x32x16_bf16 was NOT covered by the
+// compiler's hazard handling (tools/micro/split_mfma.hip returned the accumulator of one MFMA earlier), so the ReLU is the
+// integer maximum of the bit pattern against 0 there -- also one instruction, no canonicalisation, visible to the
+// compiler: negative floats (and -0) are negative integers.
 __device__ __forceinline__ float relu0(float x) {
+  if constexpr (kRcSplit) {
+    const int i = __float_as_int(x);
+    return __int_as_float(i > 0 ? i : 0);
+  }
   float y;
   asm("v_max_f32_e32 %0, 0, %1" : "=v"(y) : "v"(x));
   return y;
@@ -305,8 +480,9 @@ constexpr int kStepBias = 84;
 
 // fragment offsets of the shader's layers inside its weight stream (host: rc_api.hip, same order)
 struct ShaderFrags {
-  static constexpr int F_H = 0, F_S0 = F_H + 49, F_I0 = F_S0 + 85 * 8, F_I1 = F_I0 + 49 * 2, F_IO = F_I1 + 33 * 2,
-                       F_S1 = F_IO + 33, F_S2 = F_S1 + 65 * 4, F_SB = F_S2 + 65 * 4, F_SO = F_SB + 64 * 4, COUNT = F_SO + 3 * 64 + 3;
+  static constexpr int F_H = 0, F_S0 = F_H + rc_lfr(49, 1), F_I0 = F_S0 + rc_lfr(85, 8), F_I1 = F_I0 + rc_lfr(49, 2), F_IO = F_I1 + rc_lfr(33, 2),
+                       F_S1 = F_IO + rc_dfr(1, 2), F_S2 = F_S1 + rc_lfr(65, 4), F_SB = F_S2 + rc_lfr(65, 4), F_SO = F_SB + rc_lfr(64, 4),
+                       COUNT = F_SO + rc_dfr(3, 4);
 };
 
 struct ShaderConsts { float roughness_bias, irradiance_bias, ambient_bias, rgb_max, slf_ambient_bias; };

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
   {
     f32x16 acc[2];
     acc[0] = zero16(); acc[1] = zero16();
-    mlp_layer<2, 17, F_L2 + FR::D0, NF>(ws, act, acc);
+    mlp_layer_d<2, 17, F_L2 + FR::D0, NF>(ws, act, acc);
     uint32_t m0 = 0, m1 = 0;
     if constexpr (GRAD) {
 #pragma unroll
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
     park<2, true>(acc, act, 0);
     act[32 * 64] = h == 0 ? 1.0f : 0.0f;
     acc[0] = zero16(); acc[1] = zero16();
-    mlp_layer<2, 33, F_L2 + FR::D1, NF>(ws, act, acc);
+    mlp_layer_d<2, 33, F_L2 + FR::D1, NF>(ws, act, acc);
     if constexpr (GRAD) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -324,14 +324,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
       for (int s = 0; s < 32; ++s) bw[s * 64] = ((m1 >> s) & 1u) ? wout[s] : 0.0f;
       f32x16 g[2];
       g[0] = zero16(); g[1] = zero16();
-      mlp_layer<2, 32, F_L2 + FR::B1, NF>(ws, bw, g);
+      mlp_layer_d<2, 32, F_L2 + FR::B1, NF>(ws, bw, g);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) bw[(t * 16 + r) * 64] = ((m0 >> (t * 16 + r)) & 1u) ? g[t][r] : 0.0f;
       f32x16 gf[1];
       gf[0] = zero16();
-      mlp_layer<1, 32, F_L2 + FR::B0, NF>(ws, bw, gf);
+      mlp_layer_d<1, 32, F_L2 + FR::B0, NF>(ws, bw, gf);
       // d raw / d feature i = acc_feat(0, r, h) sits on lane (j, h): each half-wave contracts ITS 16 features with the
       // Jacobian rows parked in LDS, the two partial sums are added last (the order k_density_mlp uses)
       float gp[3] = {0.0f, 0.0f, 0.0f};

@@ -79,8 +79,77 @@ template <> struct TileMap<8> { static constexpr int NTL = 4, QS = 2; static con
 // fragments (wave 0's tile t, wave 1's tile t + QS) are read with ONE runtime-offset read when they sit in the same ring
 // chunk, and under a wave-uniform branch each when a seam separates them (a fragment of chunk c may only be read
 // between the barriers that open chunks c and c + 1).
+// Split form (rc_pack_host.h RC_SPLIT_MFMA): cells (block of 8 k-steps, tile) of three 1-KiB pieces in stream order
+// [block][tile][piece]; a slot's two candidate cells are QS * 12 fragments apart.  Every wave walks every seam.  Operand
+// registers follow the HAZARD rules of rc_dev_mlp.h: the pieces of a block are retired -- and the next loads into their
+// registers issued -- behind the first MFMAs of the block after it; NBUF register sets of pieces (three when a wave owns
+// one tile of the layer: the loads then run two blocks ahead), two of activation pieces; two flush MFMAs at the end.
+template <int NT, int KS, int FBASE>
+__device__ __forceinline__ void mlp_layer_team_split(const WStream& w, int q, const float* act, f32x16 (&acc)[TileMap<NT>::NTL]) {
+  using TM = TileMap<NT>;
+  constexpr int NTL = TM::NTL;
+  constexpr int NB = (KS + 7) / 8;
+  constexpr int NBUF = NTL == 1 ? 3 : 2, D = NBUF - 1;
+  static_assert(FBASE % 4 == 0 && kTCH % 4 == 0, "split layers start on a 1-KiB piece");
+  u32x4 a[NBUF][NTL][3], b[2][3];
+  float bv[8];
+  auto piece = [&](int fr, int off) { return lds_piece(w.ring + ((fr % (2 * kTCH)) + off) * 64 + w.lane * 4); };
+  auto load_b = [&](auto BLK) {
+    constexpr int blk = decltype(BLK)::value;
+    static_for<8>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      if constexpr (8 * blk + j < KS) bv[j] = act[(8 * blk + j) * 64];
+      else bv[j] = 0.0f;
+    });
+  };
+  auto load_a = [&](auto BLK) {
+    constexpr int blk = decltype(BLK)::value, buf = blk % NBUF;
+    static_for<NT>([&](auto T) {
+      constexpr int t = decltype(T)::value, sl = TM::slot(t);
+      static_for<3>([&](auto P) {
+        constexpr int p = decltype(P)::value, f = FBASE + ((blk * NT + t) * 3 + p) * 4;
+        if constexpr (f > 0 && f % kTCH == 0) ws_advance<kNF, kTW, kTCH>(w, f / kTCH);
+        if constexpr (TM::owner(t) == 0) {
+          constexpr int f1 = f + TM::QS * 12;          // wave 1's piece of the same slot
+          if constexpr (f / kTCH == f1 / kTCH) a[buf][sl][p] = piece(f, q * TM::QS * 12);
+          else { if (q == 0) a[buf][sl][p] = piece(f, 0); }
+        } else {
+          constexpr int f0 = f - TM::QS * 12;
+          if constexpr (f / kTCH != f0 / kTCH) { if (q == 1) a[buf][sl][p] = piece(f, 0); }
+        }
+      });
+    });
+  };
+  load_b(std::integral_constant<int, 0>{});
+  static_for<D>([&](auto I) { if constexpr (decltype(I)::value < NB) load_a(I); });
+  split8(bv, b[0]);
+  if constexpr (NB > 1) load_b(std::integral_constant<int, 1>{});
+  static_for<NB>([&](auto BLK) {
+    constexpr int blk = decltype(BLK)::value;
+    mfma_split6(a[blk % NBUF][0], b[blk & 1], acc[0]);
+    // this block's first MFMAs have issued: every MFMA of the block before has started, its registers may go
+    if constexpr (blk >= 1) {
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) split_keep3(a[(blk - 1) % NBUF][t]);
+      split_keep3(b[(blk - 1) & 1]);
+    }
+    if constexpr (blk + D < NB) load_a(std::integral_constant<int, blk + D>{});
+    if constexpr (blk + 1 < NB) {
+      split8(bv, b[(blk + 1) & 1]);
+      if constexpr (blk + 2 < NB) load_b(std::integral_constant<int, blk + 2>{});
+    }
+#pragma unroll
+    for (int t = 1; t < NTL; ++t) mfma_split6(a[blk % NBUF][t], b[blk & 1], acc[t]);
+  });
+  split_flush(w, b[(NB - 1) & 1][0]);
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) split_keep3(a[(NB - 1) % NBUF][t]);
+  split_keep3(b[(NB - 1) & 1]);
+}
+
 template <int NT, int KS, int FBASE, int SG = (TileMap<NT>::NTL >= 4 ? 2 : (TileMap<NT>::NTL >= 2 ? 4 : 8))>
 __device__ __forceinline__ void mlp_layer_team(const WStream& w, int q, const float* act, f32x16 (&acc)[TileMap<NT>::NTL]) {
+  if constexpr (kRcSplit && FBASE >= F_SH) { mlp_layer_team_split<NT, KS, FBASE>(w, q, act, acc); return; }      // density MLPs: fp32 in every build
   using TM = TileMap<NT>;
   constexpr int NTL = TM::NTL;
   constexpr int NG = (KS + SG - 1) / SG;
@@ -218,11 +287,11 @@ __device__ __forceinline__ float level_tile(const RcFusedArgs& a, const WStream&
 #endif
   f32x16 acc[2];
   acc[0] = zero16(); acc[1] = zero16();
-  mlp_layer<2, KS0, FB + FR::D0, kNF, 4, kTW, kTCH>(ws, act, acc);
+  mlp_layer_d<2, KS0, FB + FR::D0, kNF, 4, kTW, kTCH>(ws, act, acc);
   park<2, true>(acc, act, 0);
   act[32 * 64] = hh == 0 ? 1.0f : 0.0f;
   acc[0] = zero16(); acc[1] = zero16();
-  mlp_layer<2, 33, FB + FR::D1, kNF, 4, kTW, kTCH>(ws, act, acc);
+  mlp_layer_d<2, 33, FB + FR::D1, kNF, 4, kTW, kTCH>(ws, act, acc);
   float out[1], nokeep[1];
   dot_out1<2, 1, FB + FR::DO, kNF, false, kTW, 1, kTCH>(ws, acc, out, nokeep);
   return out[0];
@@ -490,7 +559,7 @@ __global__ __launch_bounds__(kTW * 64, kRays == 2 ? 2 : 1) void k_cache_fused_te
       if (q == 0) {
         f32x16 gf[1];
         gf[0] = zero16();
-        mlp_layer<1, 32, F_L2 + FR::B0, kNF, 8, kTW, kTCH>(ws, act, gf);
+        mlp_layer_d<1, 32, F_L2 + FR::B0, kNF, 8, kTW, kTCH>(ws, act, gf);
         float gp[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -518,7 +587,7 @@ __global__ __launch_bounds__(kTW * 64, kRays == 2 ? 2 : 1) void k_cache_fused_te
         ngx = rc_div(gzx, a.contract_radius); ngy = rc_div(gzy, a.contract_radius); ngz = rc_div(gzz, a.contract_radius);
         neg_normalize(ngx, ngy, ngz);
       } else {
-        tw_skip<F_L2 + FR::B0, 32>(ws);
+        tw_skip<F_L2 + FR::B0, rc_lfr32(32, 1)>(ws);
       }
       TB();                                          // wave 0 has read the backward activations
 #pragma unroll
@@ -589,7 +658,7 @@ __global__ __launch_bounds__(kTW * 64, kRays == 2 ? 2 : 1) void k_cache_fused_te
         if (p <= l - m && ((l - m - p) & 1) == 0) poly = poly + zp[p] * tb->coef[i][p];
       ide_v[i] = cpw[m] * poly;
     }
-    tw_skip<F0 + ShaderFrags::F_H, 49>(ws);          // the seams wave 0 crosses inside the heads layer
+    tw_skip<F0 + ShaderFrags::F_H, rc_lfr(49, 1)>(ws);          // the seams wave 0 crosses inside the heads layer
   }
   TB();
   if (q == 1) {

@@ -17,12 +17,12 @@ constexpr int kJac = 49;                      // act steps [49, 97): d feature /
 // fragments of the fused weight stream
 template <int KS0> struct DensFrags {
   static constexpr int NO = KS0 == 17 ? 4 : 1;       // output rows: density (+ 3 predicted normals on the last level)
-  static constexpr int D0 = 0, D1 = 2 * KS0, DO = 2 * KS0 + 66, B1 = DO + NO * 33, B0 = B1 + 64, END = B0 + 32;
+  static constexpr int D0 = 0, D1 = rc_lfr32(KS0, 2), DO = D1 + rc_lfr32(33, 2), B1 = DO + rc_dfr32(NO, 2), B0 = B1 + rc_lfr32(32, 2), END = B0 + rc_lfr32(32, 1);
 };
 constexpr int F_L0 = 0;                              // K = 6: KS0 = 4
 constexpr int F_L1 = F_L0 + DensFrags<4>::B1;        // K = 7: KS0 = 5
 constexpr int F_L2 = F_L1 + DensFrags<5>::B1;        // K = 32: KS0 = 17, with the 96 backward fragments
-constexpr int F_SH = F_L2 + DensFrags<17>::END;
+constexpr int F_SH = rc_align_piece(F_L2 + DensFrags<17>::END);      // the shader's split layers start on a whole piece
 constexpr int NF_FUSED = F_SH + ShaderFrags::COUNT;
 
 #ifdef RC_STAMPS

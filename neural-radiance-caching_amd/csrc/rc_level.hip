@@ -78,7 +78,7 @@ struct LevelK {
   static constexpr int W = LevelCfg<F>::W;
   static constexpr int K = F * NL, KS0 = (K + 1) / 2 + 1;
   static constexpr int NOB = KS0 == 17 ? 4 : 1;                            // rows the output layer was packed with
-  static constexpr int F_D0 = 0, F_D1 = 2 * KS0, F_DO = 2 * KS0 + 66, NF = F_DO + NOB * 33;
+  static constexpr int F_D0 = 0, F_D1 = rc_lfr32(KS0, 2), F_DO = F_D1 + rc_lfr32(33, 2), NF = F_DO + rc_dfr32(NOB, 2);
   static constexpr int CH = (NF / (4 * W) + 1) * 4 * W;   // > NF and a multiple of 4 W (ws_issue is instantiated, never run): the whole stream is one resident chunk
   static_assert(NF <= CH && CH % (4 * W) == 0, "stream must fit the resident chunk");
   static constexpr int kResFloats = ((NF + 3) / 4) * 4 * 64;               // [NF padded to 4][64]
@@ -204,11 +204,11 @@ struct LevelK {
     lds_sync_wave();
     f32x16 acc[2];
     acc[0] = zero16(); acc[1] = zero16();
-    mlp_layer<2, KS0, F_D0, NF, 4, W, CH>(ws, act, acc);
+    mlp_layer_d<2, KS0, F_D0, NF, 4, W, CH>(ws, act, acc);
     park<2, true>(acc, act, 0);
     act[32 * 64] = h == 0 ? 1.0f : 0.0f;
     acc[0] = zero16(); acc[1] = zero16();
-    mlp_layer<2, 33, F_D1, NF, 4, W, CH>(ws, act, acc);
+    mlp_layer_d<2, 33, F_D1, NF, 4, W, CH>(ws, act, acc);
     float out[1], nokeep[1];
     dot_out1<2, 1, F_DO, NF, false, W, NOB, CH>(ws, acc, out, nokeep);     // output_density_layer on relu(acc)
     // convert_raw_density (geometry.py:318-341)

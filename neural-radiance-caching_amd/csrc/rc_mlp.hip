@@ -40,8 +40,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
   __shared__ float lds[kWaves][kDensActSteps * 64];
   // the last level (32 grid features) also predicts the normals: 4 output rows, otherwise 1
   constexpr int NO = KS0 == 17 ? 4 : 1;
-  constexpr int F_D0 = 0, F_D1 = 2 * KS0, F_DO = 2 * KS0 + 66, F_B1 = F_DO + NO * 33, F_B0 = F_B1 + 64,
-                NF = GRAD ? F_B0 + 32 : F_B1;
+  constexpr int F_D0 = 0, F_D1 = rc_lfr32(KS0, 2), F_DO = F_D1 + rc_lfr32(33, 2), F_B1 = F_DO + rc_dfr32(NO, 2), F_B0 = F_B1 + rc_lfr32(32, 2),
+                NF = GRAD ? F_B0 + rc_lfr32(32, 1) : F_B1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
   const int64_t p0 = tile * 32;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
 
   f32x16 acc[2];
   acc[0] = zero16(); acc[1] = zero16();
-  mlp_layer<2, KS0, F_D0, NF>(ws, act, acc);
+  mlp_layer_d<2, KS0, F_D0, NF>(ws, act, acc);
   uint32_t m0 = 0, m1 = 0;           // ReLU masks, bit t*16+r
   if constexpr (GRAD) {
 #pragma unroll
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
   act[32 * 64] = h == 0 ? 1.0f : 0.0f;
 
   acc[0] = zero16(); acc[1] = zero16();
-  mlp_layer<2, 33, F_D1, NF>(ws, act, acc);
+  mlp_layer_d<2, 33, F_D1, NF>(ws, act, acc);
   if constexpr (GRAD) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -131,14 +131,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
     for (int s = 0; s < 32; ++s) act[s * 64] = ((m1 >> s) & 1u) ? wout[s] : 0.0f;
     f32x16 g[2];
     g[0] = zero16(); g[1] = zero16();
-    mlp_layer<2, 32, F_B1, NF>(ws, act, g);            // W1 . (.)   (transposed layer, no bias)
+    mlp_layer_d<2, 32, F_B1, NF>(ws, act, g);            // W1 . (.)   (transposed layer, no bias)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) act[(t * 16 + r) * 64] = ((m0 >> (t * 16 + r)) & 1u) ? g[t][r] : 0.0f;
     f32x16 gf[1];
     gf[0] = zero16();
-    mlp_layer<1, 32, F_B0, NF>(ws, act, gf);           // W0 . (.) -> d raw / d feature (32, accumulator layout)
+    mlp_layer_d<1, 32, F_B0, NF>(ws, act, gf);           // W0 . (.) -> d raw / d feature (32, accumulator layout)
     // chain through the trilinear Jacobian: this lane owns features acc_feat(0, r, h)
     float gw[3] = {0.0f, 0.0f, 0.0f};
     if (valid) {
@@ -262,8 +262,9 @@ constexpr int kEnvRingFloats = 2 * kEnvChunk * 64;
 __global__ __launch_bounds__(kEnvWaves * 64) void k_envmap(RcEnvMapArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
   constexpr int KS_IN = 15;   // 14 natural pairs of the 27 inputs (+1 zero pad) + bias
-  constexpr int F_E0 = 0, F_E1 = F_E0 + KS_IN * 8, F_E2 = F_E1 + 129 * 8, F_EB = F_E2 + 129 * 8,
-                F_EI = F_EB + 128 * 4, F_EO = F_EI + KS_IN * 4, NF = F_EO + 65;
+  constexpr int F_E0 = 0, F_E1 = F_E0 + rc_lfr(KS_IN, 8), F_E2 = F_E1 + rc_lfr(129, 8), F_EB = F_E2 + rc_lfr(129, 8),
+                F_EI = F_EB + rc_lfr(128, 4), F_EO = F_EI + rc_lfr(KS_IN, 4), NF = F_EO + rc_lfr(65, 1);
+  constexpr int H8 = rc_lfr(64, 8);          // fragments of half a 256 -> 256 layer (64 k-steps, 8 tiles)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t tile = (int64_t)blockIdx.x * kEnvWaves + wave;
   const int j = lane & 31, h = lane >> 5;
@@ -298,14 +299,14 @@ __global__ __launch_bounds__(kEnvWaves * 64) void k_envmap(RcEnvMapArgs a) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = zero16();
   mlp_layer<8, 64, F_E1, NF, 1, kEnvWaves, kEnvChunk>(ws, act, acc);
-  mlp_layer<8, 64, F_E1 + 64 * 8, NF, 1, kEnvWaves, kEnvChunk>(ws, act + 64 * 64, acc);
-  mlp_bias_step<8, F_E1 + 128 * 8, NF, kEnvWaves, kEnvChunk>(ws, acc);
+  mlp_layer<8, 64, F_E1 + H8, NF, 1, kEnvWaves, kEnvChunk>(ws, act + 64 * 64, acc);
+  mlp_bias_step<8, F_E1 + 2 * H8, NF, kEnvWaves, kEnvChunk>(ws, acc);
   park<8, true>(acc, act, 0);
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = zero16();
   mlp_layer<8, 64, F_E2, NF, 1, kEnvWaves, kEnvChunk>(ws, act, acc);
-  mlp_layer<8, 64, F_E2 + 64 * 8, NF, 1, kEnvWaves, kEnvChunk>(ws, act + 64 * 64, acc);
-  mlp_bias_step<8, F_E2 + 128 * 8, NF, kEnvWaves, kEnvChunk>(ws, acc);
+  mlp_layer<8, 64, F_E2 + H8, NF, 1, kEnvWaves, kEnvChunk>(ws, act + 64 * 64, acc);
+  mlp_bias_step<8, F_E2 + 2 * H8, NF, kEnvWaves, kEnvChunk>(ws, acc);
   park<8, true>(acc, act, 0);
   // layer_bottleneck on concat([x2 (256), inputs (27)]): x part, then the re-staged input part (+bias)
   f32x16 bt[4];

@@ -47,6 +47,34 @@ RC_HD inline bool rc_cell_corner(int N, int64_t i, int64_t* entry) {
   return inside;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Arithmetic of the MLP layers (compile-time, the whole library): RC_SPLIT_MFMA = 1 (default) runs every weight layer on
+// the bf16 matrix pipe with each fp32 operand split EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits:
+// hi + mid + lo == x bit for bit) and the six piece products whose weight is >= 2^-16 of the full product
+// (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid; what is dropped is <= 2^-23 of |a b|, the size of one fp32 rounding),
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16: 6 x 32 cycles per 16 k where v_mfma_f32_32x32x2_f32 takes 8 x 64
+// (tools/micro/split_mfma.hip: 1.9 x the layer rate at the same error against fp64).  RC_SPLIT_MFMA = 0 is the exact
+// fp32 MFMA chain of rounds 1-4 (`make diag DIAG_EXTRA=-DRC_SPLIT_MFMA=0`).
+// Stream geometry: a layer of KS k-steps (= pairs of inputs) and NT 32-row tiles is KS * NT fragments of 256 bytes in
+// the fp32 form; in the split form ceil(KS / 8) blocks x NT tiles x 3 pieces x 1 KiB (= 4 fragments each: lane l holds
+// the 8 bf16 of steps 8 q .. 8 q + 7, half l / 32, row l % 32).
+// ---------------------------------------------------------------------------------------------
+#ifndef RC_SPLIT_MFMA
+#define RC_SPLIT_MFMA 1
+#endif
+constexpr bool kRcSplit = RC_SPLIT_MFMA != 0;
+// fragments of a weight layer / of a dot_out block (NO outputs over NT hidden tiles + NO bias fragments; padded to whole
+// 1-KiB pieces in the split form so that every layer behind it starts on one)
+constexpr int rc_lfr(int ks, int nt) { return kRcSplit ? ((ks + 7) / 8) * nt * 12 : ks * nt; }
+constexpr int rc_dfr(int no, int nt) { return kRcSplit ? ((no * (nt * 16 + 1) + 3) / 4) * 4 : no * (nt * 16 + 1); }
+// The density MLPs of the proposal levels stay on the fp32 MFMA in every build (mlp_layer_d, rc_dev_mlp.h: they run in
+// kernels with two or three waves per SIMD, where the split form hit an operand hazard -- see HAZARD there): their
+// layers and dot blocks keep the fp32 geometry, and a stream that continues with split layers is padded to a whole piece.
+constexpr int rc_lfr32(int ks, int nt) { return ks * nt; }
+constexpr int rc_dfr32(int no, int nt) { return no * (nt * 16 + 1); }
+constexpr int rc_align_piece(int f) { return kRcSplit ? (f + 3) / 4 * 4 : f; }
+
 namespace rcpack {
 
 struct HostLayer {
@@ -98,7 +126,7 @@ inline Tile tile_by_reg(const std::vector<Col>& regs) {
 
 // Fragments of dot_out (rc_dev_mlp.h): per output, per tile, per accumulator register the weight of the feature that
 // register holds on each half-wave; then one bias fragment per output.
-inline std::vector<float> pack_dot(const std::vector<Col>& outs, int ntiles) {
+inline std::vector<float> pack_dot(const std::vector<Col>& outs, int ntiles, bool pad_to_piece = kRcSplit) {
   std::vector<float> v;
   for (const Col& c : outs)
     for (int t = 0; t < ntiles; ++t)
@@ -109,30 +137,68 @@ inline std::vector<float> pack_dot(const std::vector<Col>& outs, int ntiles) {
         }
   for (const Col& c : outs)
     for (int lane = 0; lane < 64; ++lane) v.push_back(c.L ? c.L->bias[c.col] : 0.0f);
+  if (pad_to_piece) v.resize((size_t)rc_dfr((int)outs.size(), ntiles) * 64, 0.0f);
   return v;
 }
 
-inline std::vector<float> pack(const std::vector<Step>& steps, const std::vector<Tile>& tiles) {
+// weight of k-step s, half-wave h, for the output row lane i of a tile holds
+inline float pack_value(const Step& st, int h, const Col& c) {
+  if (!c.L) return 0.0f;
+  const int row = st.row[h];
+  if (row == -2) return c.bias_ok ? c.L->bias[c.col] : 0.0f;
+  if (row >= 0) {
+    const int rr = row + c.row_off;
+    if (rr < c.L->in) return c.L->kernel[(size_t)rr * c.L->out + c.col];
+  }
+  return 0.0f;
+}
+
+// x == hi + mid + lo exactly, each piece the TRUNCATED top 16 bits of what is left (a bf16): 8 significand bits apiece
+inline void split3(float x, uint16_t (&piece)[3]) {
+  float r = x;
+  for (int p = 0; p < 3; ++p) {
+    uint32_t u;
+    memcpy(&u, &r, 4);
+    u &= 0xffff0000u;
+    float top;
+    memcpy(&top, &u, 4);
+    piece[p] = (uint16_t)(u >> 16);
+    r = r - top;               // exact: top shares r's leading bits
+  }
+}
+
+inline std::vector<float> pack_f32(const std::vector<Step>& steps, const std::vector<Tile>& tiles) {
   const size_t NT = tiles.size();
   std::vector<float> out(steps.size() * NT * 64, 0.0f);
   for (size_t s = 0; s < steps.size(); ++s)
     for (size_t t = 0; t < NT; ++t)
-      for (int lane = 0; lane < 64; ++lane) {
-        const int h = lane >> 5, i = lane & 31;
-        const Col& c = tiles[t][i];
-        float v = 0.0f;
-        if (c.L) {
-          const int row = steps[s].row[h];
-          if (row == -2) {
-            if (c.bias_ok) v = c.L->bias[c.col];
-          } else if (row >= 0) {
-            const int rr = row + c.row_off;
-            if (rr < c.L->in) v = c.L->kernel[(size_t)rr * c.L->out + c.col];
-          }
-        }
-        out[(s * NT + t) * 64 + lane] = v;
-      }
+      for (int lane = 0; lane < 64; ++lane) out[(s * NT + t) * 64 + lane] = pack_value(steps[s], lane >> 5, tiles[t][lane & 31]);
   return out;
+}
+
+// split form (see rc_lfr): [block q][tile t][piece p][lane][4 dwords]; dword d of a lane = bf16 of step 8 q + 2 d in the low
+// half, of step 8 q + 2 d + 1 in the high half; steps past the layer's last are zero
+inline std::vector<float> pack_split(const std::vector<Step>& steps, const std::vector<Tile>& tiles) {
+  const size_t NT = tiles.size(), NB = (steps.size() + 7) / 8;
+  std::vector<uint32_t> out(NB * NT * 3 * 64 * 4, 0u);
+  for (size_t s = 0; s < steps.size(); ++s)
+    for (size_t t = 0; t < NT; ++t)
+      for (int lane = 0; lane < 64; ++lane) {
+        uint16_t pc[3];
+        split3(pack_value(steps[s], lane >> 5, tiles[t][lane & 31]), pc);
+        const size_t q = s / 8, j = s % 8;
+        for (int p = 0; p < 3; ++p) {
+          uint32_t& d = out[((((q * NT + t) * 3 + p) * 64) + lane) * 4 + j / 2];
+          d = (j & 1) ? ((d & 0x0000ffffu) | ((uint32_t)pc[p] << 16)) : ((d & 0xffff0000u) | pc[p]);
+        }
+      }
+  std::vector<float> f(out.size());
+  memcpy(f.data(), out.data(), out.size() * 4);
+  return f;
+}
+
+inline std::vector<float> pack(const std::vector<Step>& steps, const std::vector<Tile>& tiles) {
+  return kRcSplit ? pack_split(steps, tiles) : pack_f32(steps, tiles);
 }
 
 

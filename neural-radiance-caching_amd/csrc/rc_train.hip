@@ -38,7 +38,7 @@ template <int KS0>   // k-steps of layer 0 including the bias step (4, 5 or 17)
 __global__ __launch_bounds__(kWaves * 64) void k_density_bwd(RcDensityBwdArgs a) {
   __shared__ __attribute__((aligned(16))) float ring[kRingFloats];
   __shared__ float lds[kWaves][33 * 64];
-  constexpr int F_D0 = 0, F_D1 = 2 * KS0, F_DO = F_D1 + 66, F_B1 = F_DO + 33, F_B0 = F_B1 + 64, NF = F_B0 + 32;
+  constexpr int F_D0 = 0, F_D1 = rc_lfr32(KS0, 2), F_DO = F_D1 + rc_lfr32(33, 2), F_B1 = F_DO + rc_dfr32(1, 2), F_B0 = F_B1 + rc_lfr32(32, 2), NF = F_B0 + rc_lfr32(32, 1);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
   const int64_t p0 = tile * 32;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_bwd(RcDensityBwdArgs a)
 
   f32x16 acc[2];
   acc[0] = zero16(); acc[1] = zero16();
-  mlp_layer<2, KS0, F_D0, NF>(ws, act, acc);
+  mlp_layer_d<2, KS0, F_D0, NF>(ws, act, acc);
   uint32_t m0 = 0, m1 = 0;           // ReLU masks, bit t*16+r
   float row[32];
 #pragma unroll
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_bwd(RcDensityBwdArgs a)
   act[32 * 64] = h == 0 ? 1.0f : 0.0f;
 
   acc[0] = zero16(); acc[1] = zero16();
-  mlp_layer<2, 33, F_D1, NF>(ws, act, acc);
+  mlp_layer_d<2, 33, F_D1, NF>(ws, act, acc);
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_bwd(RcDensityBwdArgs a)
   for (int s = 0; s < 32; ++s) act[s * 64] = row[s];
   f32x16 gb[2];
   gb[0] = zero16(); gb[1] = zero16();
-  mlp_layer<2, 32, F_B1, NF>(ws, act, gb);            // W1 . d2   (transposed layer, no bias)
+  mlp_layer_d<2, 32, F_B1, NF>(ws, act, gb);            // W1 . d2   (transposed layer, no bias)
 #pragma unroll
   for (int s = 0; s < 32; ++s) row[s] = ((m0 >> s) & 1u) ? gb[s >> 4][s & 15] : 0.0f;
   store_rows(a.d1, row);
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_bwd(RcDensityBwdArgs a)
   for (int s = 0; s < 32; ++s) act[s * 64] = row[s];
   f32x16 gf[1];
   gf[0] = zero16();
-  mlp_layer<1, 32, F_B0, NF>(ws, act, gf);            // W0 . d1 -> d L / d grid feature (accumulator layout)
+  mlp_layer_d<1, 32, F_B0, NF>(ws, act, gf);            // W0 . d1 -> d L / d grid feature (accumulator layout)
   if (valid) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

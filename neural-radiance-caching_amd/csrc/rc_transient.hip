@@ -38,9 +38,9 @@ constexpr int T_BENC = 93;     // [93, 101) BRDF encoding: 15 values + bias slot
 constexpr int T_SCR = 48;      // [48, 81)  scratch of the IBRDF / BRDF tails (IDE and light encoding are dead then)
 
 struct TFrags {
-  static constexpr int F_H = 0, F_IR0 = F_H + 49, F_IR1 = F_IR0 + 57 * 2, F_S0 = F_IR1 + 33 * 2, F_I0 = F_S0 + 92 * 8,
-                       F_I1 = F_I0 + 49 * 2, F_IO = F_I1 + 33 * 2, F_B0 = F_IO + 33, F_B1 = F_B0 + 56 * 2, F_BO = F_B1 + 33 * 2,
-                       F_S1 = F_BO + 33, F_S2 = F_S1 + 65 * 4, F_SB = F_S2 + 65 * 4, COUNT = F_SB + 64 * 4;
+  static constexpr int F_H = 0, F_IR0 = F_H + rc_lfr(49, 1), F_IR1 = F_IR0 + rc_lfr(57, 2), F_S0 = F_IR1 + rc_lfr(33, 2), F_I0 = F_S0 + rc_lfr(92, 8),
+                       F_I1 = F_I0 + rc_lfr(49, 2), F_IO = F_I1 + rc_lfr(33, 2), F_B0 = F_IO + rc_lfr(33, 1), F_B1 = F_B0 + rc_lfr(56, 2), F_BO = F_B1 + rc_lfr(33, 2),
+                       F_S1 = F_BO + rc_lfr(33, 1), F_S2 = F_S1 + rc_lfr(65, 4), F_SB = F_S2 + rc_lfr(65, 4), COUNT = F_SB + rc_lfr(64, 4);
 };
 
 // coord.pos_enc(x, 0, 2, append_identity=True) of a 3-vector: [x | sin(x) | sin(2x) | sin(x + pi/2) | sin(2x + pi/2)]
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_shader(RcTransShaderA
     f32x16 ib[2];
     ib[0] = zero16(); ib[1] = zero16();
     mlp_layer<2, 48, TFrags::F_I0, NF>(ws, act, ib);
-    mlp_layer<2, 1, TFrags::F_I0 + 96, NF>(ws, act + T_DOT * 64, ib);
+    mlp_layer<2, 1, TFrags::F_I0 + rc_lfr(48, 2), NF>(ws, act + T_DOT * 64, ib);
     park<2, true>(ib, act, T_SCR);
     act[(T_SCR + 32) * 64] = h == 0 ? 1.0f : 0.0f;
     ib[0] = zero16(); ib[1] = zero16();
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_shader(RcTransShaderA
     f32x16 b[2];
     b[0] = zero16(); b[1] = zero16();
     mlp_layer<2, 48, TFrags::F_B0, NF>(ws, act, b);
-    mlp_layer<2, 8, TFrags::F_B0 + 96, NF>(ws, act + T_BENC * 64, b);
+    mlp_layer<2, 8, TFrags::F_B0 + rc_lfr(48, 2), NF>(ws, act + T_BENC * 64, b);
     park<2, true>(b, act, T_SCR);
     act[(T_SCR + 32) * 64] = h == 0 ? 1.0f : 0.0f;
     b[0] = zero16(); b[1] = zero16();

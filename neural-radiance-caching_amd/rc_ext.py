@@ -147,7 +147,7 @@ class rc_cast_outputs(C.Structure):
 
 
 EXPORTS = (
-    "rc_create", "rc_destroy", "rc_last_error", "rc_abi_version", "rc_load_weights", "rc_render_rays", "rc_render_chunks",
+    "rc_create", "rc_destroy", "rc_last_error", "rc_abi_version", "rc_mlp_arithmetic", "rc_load_weights", "rc_render_rays", "rc_render_chunks",
     "rc_hashgrid_lookup", "rc_sample_intervals", "rc_workspace_ptr", "rc_set_profiling", "rc_stage_count",
     "rc_stage_name", "rc_stage_times_ms", "rc_set_graph_mode", "rc_set_fused", "rc_render_material", "rc_set_transient", "rc_render_transient", "rc_cast_rays",
     "rc_prng_fill", "rc_density_grad_size", "rc_density_grad_layout", "rc_density_backward",
@@ -161,6 +161,11 @@ _RAY_FIELDS = ("origins", "directions", "viewdirs", "near", "far", "lights", "no
 def library_path() -> str:
     # RC_HIP_LIBRARY: a diagnostic / A-B build of the same ABI (tools/README.md); the product is the in-tree library
     return os.environ.get("RC_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librc_hip.so")
+
+
+def mlp_arithmetic() -> str:
+    """'f32-mfma' or 'bf16x3-split' (include/rc_abi.h rc_mlp_arithmetic): how the loaded library multiplies in the shader MLPs."""
+    return "bf16x3-split" if load_library().rc_mlp_arithmetic() == 1 else "f32-mfma"
 
 
 def source_hash() -> str:
@@ -196,6 +201,7 @@ def load_library():
     lib.rc_last_error.argtypes = [C.c_void_p]
     lib.rc_last_error.restype = C.c_char_p
     lib.rc_abi_version.restype = C.c_int
+    lib.rc_mlp_arithmetic.restype = C.c_int
     lib.rc_load_weights.argtypes = [C.c_void_p, C.POINTER(rc_tensor_desc), C.c_int32]
     lib.rc_load_weights.restype = C.c_int
     lib.rc_render_rays.argtypes = [C.c_void_p, C.POINTER(rc_rays), C.c_int64, C.POINTER(rc_randoms), C.c_uint32,

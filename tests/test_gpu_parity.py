@@ -162,6 +162,34 @@ def test_cache_render_256_vs_oracle_fp32(rc, jitter_seed):
     assert np.abs(d0 - ref["sampler"][0]["density"].numpy()).max() <= 1e-4
 
 
+@pytest.mark.parametrize("jitter_seed", [None, 7])
+def test_intermediates_sit_at_the_fp32_noise_floor_of_the_oracle(rc, jitter_seed):
+    """The keys the test above holds to looser-than-1e-4 bounds (geometry 5e-4, distances 1e-3, the samplers' step functions),
+    measured against what fp32 arithmetic in the reference's OWN order loses: the fp64 oracle is the exact value, the fp32
+    oracle's distance from it is the floor, and the HIP path may be no more than 3 x that floor away from the exact value
+    (measured 0.6-1.4 x: profiles/r04_tolerance_floor.txt, tools/measure_tolerances.py).  An error of the kernels' own -- a
+    wrong constant, a dropped term -- is orders of magnitude above the floor; a bound of 1e-3 would let one of 5e-4 through."""
+    n = 256
+    out = _render(rc, n, jitter_seed, fused=False)
+    r32 = common.oracle_cache(n, jitter_seed=jitter_seed, want_grad_normals=False)
+    r64 = common.oracle_cache(n, jitter_seed=jitter_seed, want_grad_normals=False, dtype=torch.float64)
+
+    def check(name, a, b32, b64):
+        a = a.astype(np.float64)
+        b32, b64 = np.asarray(b32, np.float64).reshape(a.shape), np.asarray(b64, np.float64).reshape(a.shape)
+        floor, err = np.abs(b32 - b64).max(), np.abs(a - b64).max()
+        assert err <= 3.0 * floor + 1e-7, (name, err, floor)
+
+    for k in ("rgb", "acc", "means", "normals_pred", "ray_dists", "light_dists", "distance_mean", "distance_median",
+              "distance_percentile_5", "distance_percentile_95"):
+        b32, b64 = r32["render"][k].numpy(), r64["render"][k].numpy()
+        if k in ("ray_dists", "light_dists"): b32, b64 = b32[:, 0], b64[:, 0]
+        check(k, out[k], b32, b64)
+    for l, S in enumerate((64, 64, 32)):
+        for w, cols in (("sdist", S + 1), ("tdist", S + 1), ("weights", S), ("density", S)):
+            check(f"{w}{l}", rc.workspace(f"{w}{l}").reshape(n, cols), r32["sampler"][l][w].numpy(), r64["sampler"][l][w].numpy())
+
+
 @pytest.mark.parametrize("name", ["hotdog_cache_256_det.npz", "hotdog_cache_256_jit.npz"])
 def test_cache_render_vs_fp64_golden(rc, name):
     g = dict(np.load(os.path.join(GOLD, name)))
@@ -984,6 +1012,31 @@ def test_transient_render_image_keys_and_shapes():
     # chunk 0 (16 rays) of the image == the same 16 rays rendered directly
     direct = m.rc.render_transient({k: np.asarray(v)[:16] for k, v in flat.hot_fields().items()}, None, outputs=["rgb"])
     assert np.array_equal(img["rgb"].reshape(H * W, 700, 3)[:16], direct["rgb"].cpu().numpy())
+
+
+@pytest.mark.parametrize("n,plan", [(4097, 1), (4097, 0), (25001, 1)])
+def test_repeated_launches_are_bitwise_stable_with_workgroups_out_of_phase(rc, n, plan):
+    """More rays than one round of workgroups: those sharing a CU then run DIFFERENT phases of the kernel at the same time.
+    This is the screen that caught the operand hazard of the split-MFMA form with two waves per SIMD (csrc/rc_dev_mlp.h
+    HAZARD, tools/stress_repeat.py: one ray in a few hundred off by 1e-3 in most launches of a 4097-ray batch); the plans
+    the library runs must come out bit for bit the same every time."""
+    from nrc_amd import rc_ext
+    assert rc_ext.mlp_arithmetic() in ("f32-mfma", "bf16x3-split")
+    rays = nrc_amd.synthetic_rays(n, seed=78)
+    f = {k: torch.from_numpy(np.asarray(v)).cuda().contiguous() for k, v in rays.hot_fields().items()}
+    rnd = {"jitter": [torch.from_numpy(j).cuda() for j in common.jitters(n, seed=6)]}
+    rc.set_graph_mode(0)
+    rc.set_fused(plan)
+    try:
+        first = {k: v.clone() for k, v in rc.render_rays(f, rnd).items()}
+        for it in range(12 if n < 10000 else 4):
+            out = rc.render_rays(f, rnd)
+            torch.cuda.synchronize()
+            for k, v in out.items():
+                assert torch.equal(v, first[k]), (it, k, float((v - first[k]).abs().max()))
+    finally:
+        rc.set_fused(True)
+        rc.set_graph_mode(1)
 
 
 def test_repeated_launches_are_bitwise_stable(rc):

@@ -37,6 +37,29 @@ def np_pack(steps, tiles, layers):
     return out.reshape(-1)
 
 
+def unsplit(words, n_steps, n_tiles):
+    """The split form of a layer (rc_pack_host.h pack_split: [block of 8 k-steps][tile][piece][lane][4 dwords], a dword = the
+    bf16 of an even step in its low half and of the following step in its high half) back to [step][tile][lane] float32:
+    the three pieces must add up to the packed weight EXACTLY, each must be the truncated top 16 bits of what the pieces
+    in front of it leave, and the steps that pad the last block must be zero."""
+    nb = (n_steps + 7) // 8
+    w = np.asarray(words).view(np.uint32).reshape(nb, n_tiles, 3, 64, 4)
+    halves = np.stack([w & 0xFFFF, w >> 16], axis=-1).reshape(nb, n_tiles, 3, 64, 8)          # [..., j] = step 8 q + j
+    pieces = (halves.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    total = pieces.sum(axis=2)                                                                 # exact in float64
+    val = total.astype(np.float32)
+    assert np.array_equal(val.astype(np.float64), total)
+    rest = val.astype(np.float32)
+    for p in range(3):
+        top = (rest.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+        assert np.array_equal(top.astype(np.float64), pieces[:, :, p])
+        rest = (rest - top).astype(np.float32)
+    assert not rest.any()
+    out = val.transpose(0, 3, 1, 2).reshape(nb * 8, n_tiles, 64)                                # [step][tile][lane]
+    assert not out[n_steps:].any()
+    return out[:n_steps].reshape(-1)
+
+
 def natural(K):
     return [(2 * i, 2 * i + 1 if 2 * i + 1 < K else -1) for i in range((K + 1) // 2)]
 
@@ -73,10 +96,10 @@ def _out(d, name):
 def test_fragment_packing_matches_numpy(hostcheck):
     d, layers, _ = hostcheck
     want = np_pack(natural(37) + [(-2, -1)], [full_tile("a", t, 70) for t in range(3)], layers)
-    assert np.array_equal(_out(d, "pack"), want)
+    assert np.array_equal(unsplit(_out(d, "pack"), 20, 3), want)
     acc_steps = [(acc_feat(t, r, 0), acc_feat(t, r, 1)) for t in range(2) for r in range(16)]
     want = np_pack(acc_steps, [full_tile("b", t, 40, False) for t in range(2)], layers)
-    assert np.array_equal(_out(d, "pack_acc"), want)
+    assert np.array_equal(unsplit(_out(d, "pack_acc"), 32, 2), want)
     # "by register": output r sits in accumulator register r of BOTH half-waves = tile rows (r & 3) + 8 (r >> 2) + 4 h
     tile = [None] * 32
     for i in range(32):
@@ -84,7 +107,7 @@ def test_fragment_packing_matches_numpy(hostcheck):
         if r < 5:
             tile[i] = ("c", r, True)
     want = np_pack(natural(9) + [(-2, -1)], [tile], layers)
-    assert np.array_equal(_out(d, "by_reg"), want)
+    assert np.array_equal(unsplit(_out(d, "by_reg"), 6, 1), want)
 
 
 def test_dot_fragments_match_numpy(hostcheck):
@@ -97,7 +120,9 @@ def test_dot_fragments_match_numpy(hostcheck):
                 want.append([k[acc_feat(t, r, lane >> 5), o] for lane in range(64)])
     for o in range(3):
         want.append([b[o]] * 64)
-    assert np.array_equal(_out(d, "dot"), np.asarray(want, np.float32).reshape(-1))
+    want = np.asarray(want, np.float32).reshape(-1)
+    got = _out(d, "dot")                     # padded with zero fragments to whole 1-KiB pieces (rc_dfr)
+    assert got.size == (3 * 33 + 3) // 4 * 4 * 64 and np.array_equal(got[:want.size], want) and not got[want.size:].any()
 
 
 def test_folded_bottleneck_matches_fp64_product(hostcheck):
