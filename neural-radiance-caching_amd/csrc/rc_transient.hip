@@ -309,8 +309,12 @@ constexpr int kBins = 700;
 constexpr int kHist = kBins * 3;                 // 2100 histogram entries per ray, entry = bin * 3 + channel
 constexpr int kTilesB = (kHist + 31) / 32;       // 66 column tiles
 constexpr int kTileFrags = 65 + 33;              // SLF output layer (128 + bias) | transient_indirect_layer (64 + bias)
-constexpr int kFragsPerTile = 2 * kChunk;        // padded to two whole chunks of the LDS ring: the chunk seams sit at
+// split form (rc_pack_host.h): 9 + 5 blocks of 8 k-steps x 3 pieces x 4 fragments = 168 fragments per tile
+constexpr int kTileFragsSplit = (rc_lfr(65, 1) + rc_lfr(33, 1));
+constexpr int kChunksPerTile = kRcSplit ? 3 : 2;
+constexpr int kFragsPerTile = kChunksPerTile * kChunk;   // padded to whole chunks of the LDS ring: the chunk seams sit at
                                                  // compile-time positions of a tile (no per-fragment seam test)
+static_assert(!kRcSplit || kTileFragsSplit <= kFragsPerTile, "a tile's pieces fit its chunks");
 static_assert(kTileFrags <= kFragsPerTile, "a tile's fragments fit its two chunks");
 constexpr int kBinFrags = kTilesB * kFragsPerTile;
 constexpr int kSP = 10;                          // per-sample parameters kept in LDS
@@ -352,18 +356,49 @@ __device__ __forceinline__ void ws_issue_rt(const WStream& w, int c, int nf) {
 // fragment J of column tile T of the stream.  T is a run-time value, J a constant once the callers' loops are
 // unrolled: a tile is exactly two chunks of the ring, so the seam test folds away and the waits / barriers sit at
 // J = 0 and J = kChunk of every tile
-__device__ __forceinline__ float ws_tile_frag(const WStream& w, int T, int J, int nf, int c0) {
-  static_assert(kFragsPerTile == 2 * kChunk, "tile = two chunks");
+__device__ __forceinline__ void ws_tile_seam(const WStream& w, int T, int J, int nf, int c0) {
   if (J % kChunk == 0) {
-    const int c = 2 * T + J / kChunk;
+    const int c = kChunksPerTile * T + J / kChunk;
     if (c > c0) {         // c0: the first chunk of this launch's tile range (in flight since the prologue)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if ((c + 1) * kChunk < nf) ws_issue_rt(w, c + 1, nf);
     }
   }
+}
+__device__ __forceinline__ float ws_tile_frag(const WStream& w, int T, int J, int nf, int c0) {
+  static_assert(kRcSplit || kFragsPerTile == 2 * kChunk, "fp32 form: tile = the two chunks of the ring, J is the ring slot");
+  ws_tile_seam(w, T, J, nf, c0);
   return w.ring[J * 64 + w.lane];
 }
+// split form: the 1-KiB piece at fragments [J, J + 4) of tile T (three chunks per tile: the ring half of a chunk follows
+// the parity of its number, a run-time value)
+__device__ __forceinline__ u32x4 ws_tile_piece(const WStream& w, int T, int J, int nf, int c0) {
+  ws_tile_seam(w, T, J, nf, c0);
+  const int c = kChunksPerTile * T + J / kChunk;
+  return lds_piece(w.ring + ((c & 1) * kChunk + J % kChunk) * 64 + w.lane * 4);
+}
+
+// Split form of tile_xw2 below: the activations of the two heads were split once per ray (xsp: 9 blocks, xip: 5), the
+// weights of the tile come as pieces in the order [SLF head blocks 0-8 | irradiance head blocks 0-4]; six products per
+// block and head, one accumulation chain per head (a chain of this MFMA needs no second one beside it).
+__device__ __forceinline__ void tile_xw2_split(const WStream& w, int T, int nf, int c0, const u32x4 (&xsp)[9][3], const u32x4 (&xip)[5][3],
+                                               f32x16& as, f32x16& ai) {
+  constexpr int NCELL = 14;
+  u32x4 b[2][3];
+  auto load = [&](int cell, int buf) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) b[buf][p] = ws_tile_piece(w, T, (cell * 3 + p) * 4, nf, c0);
+  };
+  load(0, 0);
+#pragma unroll
+  for (int cell = 0; cell < NCELL; ++cell) {
+    if (cell + 1 < NCELL) load(cell + 1, (cell + 1) & 1);
+    if (cell < 9) mfma_split6(xsp[cell], b[cell & 1], as);
+    else mfma_split6(xip[cell - 9], b[cell & 1], ai);
+  }
+}
+
 
 // X W of one column tile for both heads: 65 k-steps of the SLF head (xs -> as) and 33 of the irradiance head
 // (xi -> ai).  The two accumulator chains are interleaved 4 : 2 (a chain's next MFMA waits for its previous one; the
@@ -481,7 +516,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
   // tile of entry f = 3 b + c is f / 32; groups of three tiles (T3) keep the channel phase of a lane a constant
   const int T3_lo = blo <= bhi ? ((3 * blo) / 32) / 3 : 0;
   const int T3_hi = blo <= bhi ? min(kTilesB / 3 - 1, ((3 * bhi + 2) / 32 + 1) / 3) : -1;
-  const int c0 = 2 * (3 * T3_lo);
+  const int c0 = kChunksPerTile * (3 * T3_lo);
   if (T3_hi >= T3_lo) ws_issue_rt(ws, c0, kBinFrags);
   // activations of the two output layers (this ray's 32 samples), with the bias step
   float xs[65], xi[33];
@@ -494,6 +529,24 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (T3_hi >= T3_lo && (c0 + 1) * kChunk < kBinFrags) ws_issue_rt(ws, c0 + 1, kBinFrags);
+  // split form: the three bf16 pieces of every activation, once for all 66 column tiles
+  u32x4 xsp[kRcSplit ? 9 : 1][3], xip[kRcSplit ? 5 : 1][3];
+  if constexpr (kRcSplit) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 8 * q + j < 65 ? xs[8 * q + j] : 0.0f;
+      split8(v, xsp[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 8 * q + j < 33 ? xi[8 * q + j] : 0.0f;
+      split8(v, xip[q]);
+    }
+  }
 
   // per-sample sums over the bins: by tile phase u = T % 3 (the channel of a lane's entry is (2 u + fl) % 3)
   float sd[3][16], ss[3][16];
@@ -537,7 +590,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs 
 #endif
       RC_BSTAMP(q0);
       f32x16 as = zero16(), ai = zero16();
-      tile_xw2(ws, T, kBinFrags, c0, xs, xi, as, ai);
+      if constexpr (kRcSplit) tile_xw2_split(ws, T, kBinFrags, c0, reinterpret_cast<const u32x4 (&)[9][3]>(xsp), reinterpret_cast<const u32x4 (&)[5][3]>(xip), as, ai);
+      else tile_xw2(ws, T, kBinFrags, c0, xs, xi, as, ai);
       RC_BSTAMP(q1);
       const int f = T * 32 + fl;                   // histogram entry of this lane
       const bool fok = f < kHist;

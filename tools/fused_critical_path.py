@@ -1,4 +1,8 @@
-"""Where the 124 us of k_cache_fused_team go: per phase and per wave role, measured with in-kernel stamps.
+"""Where the time of the fused cache kernel goes: per phase (and per wave role, for the two-wave kernel of fp32-MFMA
+builds), measured with in-kernel stamps.  A split-MFMA build (rc_ext.mlp_arithmetic() == "bf16x3-split") runs the
+one-wave-per-ray kernel: one column of waves, one wave per SIMD, MFMA issue = 64 cycles per fp32 MFMA of the density MLPs
+(two 32-sample tiles per wave on the proposal levels: 148 / 152, the last level with its backward pass 196) and 32 cycles
+per bf16 MFMA of the shader (223 cells x 6 products + 2 flush MFMAs per layer = 1352).
 
 Needs two diagnostic builds of the library (tools/prof_round.sh builds them):
     make -C neural-radiance-caching_amd/csrc diag                                          -> tools/diag/librc_hip.so
@@ -56,6 +60,8 @@ np.save({out!r}, buf.cpu().numpy().reshape(2, {N}, 16))
     return d
 
 
+SPLIT = rc_ext.mlp_arithmetic() == "bf16x3-split"
+MFMA_CYC = [0, 0, 148 * 64, 0, 0, 152 * 64, 0, 0, 196 * 64, 1352 * 32, 0] if SPLIT else [m * 64 * 2 for m in MFMA]
 real = run(os.path.join(R, "tools", "diag", "librc_hip.so"))
 fake = run(os.path.join(R, "tools", "diag", "fake", "librc_hip.so"))
 tot = real[0][:, 11] - real[0][:, 0]
@@ -66,16 +72,18 @@ print(f"clock {ghz:.3f} GHz; launch span (first start -> last end) {(real[0][:, 
       f"{(fake[0][:, 15].max() - fake[0][:, 14].min()) / 100.0:.1f} us without memory time; source {rc_ext.source_hash()}")
 print(f"{'phase':16s} | {'wave 0: measured':>16s} {'no-memory':>10s} {'mem wait':>9s} | {'wave 1: measured':>16s} {'no-memory':>10s} {'mem wait':>9s} | {'MFMA issue':>10s} {'other':>7s}")
 sums = np.zeros(8)
+two = bool(real[1][:, 11].any())            # the one-wave kernel leaves the second half of the stamp buffer untouched
+if not two: print("(one wave per ray: the wave-1 columns repeat wave 0)")
 for i, nm in enumerate(NAMES):
     row = []
-    for q in (0, 1):
+    for q in ((0, 1) if two else (0, 0)):
         m = float(np.median(real[q][:, i + 1] - real[q][:, i])); f = float(np.median(fake[q][:, i + 1] - fake[q][:, i]))
         row += [us(m), us(f), us(m) - us(f)]
-    mf = us(MFMA[i] * 64 * 2)
+    mf = us(MFMA_CYC[i])
     other = row[1] - mf
     print(f"{nm:16s} | {row[0]:16.2f} {row[1]:10.2f} {row[2]:9.2f} | {row[3]:16.2f} {row[4]:10.2f} {row[5]:9.2f} | {mf:10.2f} {other:7.2f}")
     sums += np.array(row + [mf, other])
 print(f"{'sum':16s} | {sums[0]:16.2f} {sums[1]:10.2f} {sums[2]:9.2f} | {sums[3]:16.2f} {sums[4]:10.2f} {sums[5]:9.2f} | {sums[6]:10.2f} {sums[7]:7.2f}")
 print(f"per-ray total (stamp 0 -> 11), median: wave 0 {us(float(np.median(tot))):.2f} us; the phases above are {sums[0] / us(float(np.median(tot))) * 100:.1f} % of it")
 hb = real[0][:, 12].astype(np.float64)
-print(f"hand-off barriers of wave 0: {int(np.median(real[0][:, 13].astype(np.int64) >> 32))} per ray, waited {us(float(np.median(hb))):.2f} us (median; arrival skew + the fence's drain)")
+if two: print(f"hand-off barriers of wave 0: {int(np.median(real[0][:, 13].astype(np.int64) >> 32))} per ray, waited {us(float(np.median(hb))):.2f} us (median; arrival skew + the fence's drain)")
