@@ -1723,7 +1723,9 @@ int rc_render_material(rc_handle* h, const rc_rays* rays, int64_t n, const rc_ra
     // miss; the LAST level (F = 4) is bound by the fabric's random-sector rate, not by CUs.  So the EnvMap is released when
     // that level is launched, and that launch leaves it a quarter of the CUs (RC_ENV_RESERVE overrides; 0 = beside the
     // first level as before): 1.48 -> 1.45 ms per step (reserve 32 / 64 / 96 of 256: 1.463 / 1.447-1.456 / 1.508).
-    static const int env_reserve = getenv("RC_ENV_RESERVE") ? atoi(getenv("RC_ENV_RESERVE")) : rc_device_cus() / 4;
+    // (split-MFMA build: the EnvMap takes 0.7 of the time on the bf16 pipe and an eighth of the CUs is enough -- 16 ... 40 of
+    // 256 measure 1.315-1.33 ms per step, 64: 1.36, 80: 1.38)
+    static const int env_reserve = getenv("RC_ENV_RESERVE") ? atoi(getenv("RC_ENV_RESERVE")) : rc_device_cus() / (kRcSplit ? 8 : 4);
     const bool beside_last = env_reserve > 0 && nsec >= 24576 && (h->fused_mode == 1 || h->fused_mode == 3);
     bool env_released = false;
     if (beside_last) {

@@ -1,6 +1,8 @@
-// Fused cache forward for primary rays, TWO wavefronts per ray and TWO workgroups per CU (the plain cache pass of
-// BASELINE configs 1, 2, 4; rc_fused.hip is the one-wavefront-per-ray form the transient front end and the material
-// stage's export still use).
+// Fused cache forward for primary rays, TWO wavefronts per ray and TWO workgroups per CU: the plain cache pass of
+// BASELINE configs 1, 2, 4 in builds with the fp32-MFMA shader (RC_SPLIT_MFMA=0).  The default build runs the shader on
+// the bf16 pipe (rc_dev_mlp.h, split form) and the one-wavefront-per-ray kernel of rc_fused.hip for this pass too: the
+// split form hit an operand hazard with two waves per SIMD (HAZARD there; RC_TEAM_SPLIT=1 puts this kernel back for
+// diagnosis).  rc_fused.hip is also the transient front end and the material stage's export.
 //
 // Why: with one wavefront per ray a 1024-ray batch is one wave per SIMD, and everything a wave waits for -- the
 // texture-address unit working through 10 752 divergent lane requests per ray (the gather phases run at the CU's ~1

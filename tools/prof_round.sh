@@ -38,8 +38,8 @@ for set in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_
   echo "$tag done"
 done
 cd $ROOT
-python tools/prof_to_json.py $O $O/pmc_k_cache_fused.json
-python tools/pmc_table.py $O "mat_*" > $O/material_pmc_counters.txt
+python tools/prof_to_json.py $O $O/pmc_k_cache_fused.json || echo "prof_to_json failed"
+python tools/pmc_table.py $O "mat_*" > $O/material_pmc_counters.txt || echo "pmc_table failed"
 if [ -f tools/diag/librc_hip.so ]; then
   python tools/gpu_stamps_fused.py 1024 "" $O/fused_phase_stamps.json > $O/fused_phase_stamps.txt
   RC_STAMP_RAYS=tile python tools/gpu_stamps_fused.py 1024 "" $O/fused_phase_stamps_tile.json > $O/fused_phase_stamps_tile.txt

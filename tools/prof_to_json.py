@@ -20,7 +20,9 @@ from nrc_amd import rc_ext  # noqa: E402
 
 def main():
     prof, out = sys.argv[1], sys.argv[2]
-    kernel = sys.argv[3] if len(sys.argv) > 3 else "k_cache_fused_team<true>"
+    # the dominant kernel of the default plan: the one-wave-per-ray kernel in a split-MFMA build, the two-wave kernel otherwise
+    default = "k_cache_fused<true" if rc_ext.mlp_arithmetic() == "bf16x3-split" else "k_cache_fused_team<true>"
+    kernel = sys.argv[3] if len(sys.argv) > 3 else default
     acc = defaultdict(list)
     for p in glob.glob(os.path.join(prof, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(p)):
