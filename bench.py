@@ -381,7 +381,7 @@ def main():
     fused_mode = {"fused": 1, "fused1": 3, "staged": 0}[args.plan]
     rc.set_fused(fused_mode)
     # how the library multiplies in the shader MLPs (include/rc_abi.h rc_mlp_arithmetic).  A bf16x3-split build runs the
-    # one-wave-per-ray kernel for the default plan too: the two-wave kernel puts two waves on a SIMD
+    # one-wave-per-ray kernel for the default plan too (the two-wave kernel was unstable under the split form)
     arith = rc_ext.mlp_arithmetic()
     dominant = {"fused": "k_cache_fused" if arith == "bf16x3-split" else "k_cache_fused_team", "fused1": "k_cache_fused",
                 "staged": "k_cache_shader"}[args.plan]

@@ -1111,9 +1111,9 @@ void enqueue_all(rc_handle* h, const RenderArgs& A, hipStream_t st) {
     F.out = A.out;
     F.direct = h->fused_direct;
     // mode 3: the one-wavefront-per-ray form.  Builds with the split-MFMA shader (RC_SPLIT_MFMA) run it for mode 1 as well:
-    // the two-wave kernel puts two waves on a SIMD, where the split form hit an operand hazard (rc_dev_mlp.h HAZARD)
+    // the two-wave kernel was unstable with the split form in every layer (rc_dev_mlp.h INSTABILITY; cause not found)
     // (RC_TEAM_SPLIT=1 in the environment puts the two-wave kernel back under the split form: the configuration
-    // tools/stress_repeat.py shows the hazard on -- for diagnosis only, its results are wrong in one ray of a few hundred)
+    // for diagnosis: with the density MLPs fp32, as they are now, tools/stress_repeat.py has not shown a differing launch there)
     static const bool team_split = getenv("RC_TEAM_SPLIT") && getenv("RC_TEAM_SPLIT")[0] == '1';
     F.team = (h->fused_mode == 1 && (!kRcSplit || team_split)) ? 1 : 0;
     F.stagger_cycles = h->fused_stagger;

@@ -46,23 +46,28 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&b)[3]) {
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-// HAZARD (measured, ROCm 7.2 / gfx950; tools/stress_repeat.py, profiles/r04_split_mfma_hazard.txt): with two or more
-// waves per SIMD a v_mfma_f32_32x32x16_bf16 does not always fetch its A / B operands at issue -- while the matrix pipe
-// runs another wave's MFMA it stays pending and fetches them when it starts.  An instruction of the same wave that
-// overwrites an operand register in between changes the product (the compiler reuses the registers of a cell's pieces
-// for the next block's split a few instructions behind the MFMA: it knows no such hazard, and its wait states for the
-// accumulators count from the ISSUE of the last MFMA).  Seen as one ray in a few hundred off by ~1e-3 in some launches,
-// never with one wave per SIMD, never with the 16-pass fp32 MFMA (it holds the SIMD's vector issue while it runs).
-// The rules below need no timing assumption, only that a wave's MFMA issues once its previous one has started and that
-// the matrix pipe runs a wave's MFMAs in order:
+// INSTABILITY and the rules below (tools/stress_repeat.py, profiles/r04_split_mfma_hazard.txt).  What is measured:
+//  * With the layers written plainly (pieces prefetched one cell ahead, the compiler free to schedule), results differ
+//    from launch to launch in a few rays of a few hundred by ~1e-3 wherever waves of more than one workgroup or kernel
+//    share a SIMD with a split layer: the two-wave kernel of rc_fused2.hip (two workgroups per CU), and even the kernels
+//    with one 4-wave workgroup per CU when another stream's or the material stage's concurrent kernel lands on their CU
+//    (5 of the 129 GPU tests: the multi-stream and the material launch-plan tests).  Never with a kernel alone on its CUs,
+//    never with the fp32 MFMA.
+//  * The obvious cause -- the bf16 MFMA fetching operands or delivering results late beside another wave's MFMAs, with
+//    the compiler reusing an operand register one instruction behind it -- does NOT show in isolation:
+//    tools/micro/mfma_pending.hip overwrites an operand 0 wait states behind the MFMA and reads accumulators 8 wait states
+//    behind it, beside idle and MFMA-hogging partner waves, and every sum is right (profiles/r04_mfma_pending_probe.txt).
+//  * With the three rules below the full GPU suite and the repeat screen pass (129 tests, every plan and size bitwise
+//    stable), except for the two-wave kernel with EVERY layer split at 4097+ rays -- which is why the density MLPs stay
+//    fp32 (mlp_layer_d) and a split build does not run that kernel (rc_api.hip).
+// So the rules are empirical: they are what separates the stable from the unstable form here, the mechanism is not
+// established.  They cost nothing measurable.
 //  1. the MFMAs of a cell issue back to back (scheduling barriers), nothing of the wave in between;
 //  2. the operand registers of a cell stay live (split_keep: an empty asm that reads them) until the MFMAs of the NEXT
-//     cell have issued -- by then every MFMA of the cell has started; weight pieces rotate through three register sets,
-//     activation pieces through two, loads and splits into a set follow the marker that retires it;
+//     cell have issued; weight pieces rotate through three register sets, activation pieces through two, loads and
+//     splits into a set follow the marker that retires it;
 //  3. behind a layer's last cell two flush MFMAs (16x16x32 into a 4-register sink that lives as long as the stream
-//     object and is never read) issue before the accumulators are read or the last operands are released: the second
-//     issues once the first has started, i.e. once every MFMA of the layer has finished.  A flush fetching stale
-//     operands or completing late only touches the sink.
+//     object and is never read) issue before the accumulators are read or the last operands are released.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split_keep(const u32x4& x) { asm volatile("" ::"v"(x)); }
 __device__ __forceinline__ void split_keep3(const u32x4 (&x)[3]) { asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(x[2])); }
@@ -104,7 +109,7 @@ struct WStream {
   const float* g;    // packed fragment stream (padded to a whole number of chunks)
   float* ring;       // LDS ring [2 * kChunk][64]
   int lane, wave;
-  mutable f32x4 sink = {0.0f, 0.0f, 0.0f, 0.0f};     // split form: destination of the flush MFMAs (see HAZARD above), never read
+  mutable f32x4 sink = {0.0f, 0.0f, 0.0f, 0.0f};     // split form: destination of the flush MFMAs (see INSTABILITY above), never read
   __device__ WStream() = default;
   __device__ WStream(const float* g_, float* ring_, int lane_, int wave_) : g(g_), ring(ring_), lane(lane_), wave(wave_) {}
 };

@@ -1,7 +1,7 @@
 // Fused cache forward for primary rays, TWO wavefronts per ray and TWO workgroups per CU: the plain cache pass of
 // BASELINE configs 1, 2, 4 in builds with the fp32-MFMA shader (RC_SPLIT_MFMA=0).  The default build runs the shader on
 // the bf16 pipe (rc_dev_mlp.h, split form) and the one-wavefront-per-ray kernel of rc_fused.hip for this pass too: the
-// split form hit an operand hazard with two waves per SIMD (HAZARD there; RC_TEAM_SPLIT=1 puts this kernel back for
+// kernel was unstable with the split form in every layer (INSTABILITY there; RC_TEAM_SPLIT=1 puts it back for
 // diagnosis).  rc_fused.hip is also the transient front end and the material stage's export.
 //
 // Why: with one wavefront per ray a 1024-ray batch is one wave per SIMD, and everything a wave waits for -- the
@@ -83,7 +83,7 @@ template <> struct TileMap<8> { static constexpr int NTL = 4, QS = 2; static con
 // between the barriers that open chunks c and c + 1).
 // Split form (rc_pack_host.h RC_SPLIT_MFMA): cells (block of 8 k-steps, tile) of three 1-KiB pieces in stream order
 // [block][tile][piece]; a slot's two candidate cells are QS * 12 fragments apart.  Every wave walks every seam.  Operand
-// registers follow the HAZARD rules of rc_dev_mlp.h: the pieces of a block are retired -- and the next loads into their
+// registers follow the rules of rc_dev_mlp.h (INSTABILITY): the pieces of a block are retired -- and the next loads into their
 // registers issued -- behind the first MFMAs of the block after it; NBUF register sets of pieces (three when a wave owns
 // one tile of the layer: the loads then run two blocks ahead), two of activation pieces; two flush MFMAs at the end.
 template <int NT, int KS, int FBASE>

@@ -68,8 +68,8 @@ constexpr bool kRcSplit = RC_SPLIT_MFMA != 0;
 // 1-KiB pieces in the split form so that every layer behind it starts on one)
 constexpr int rc_lfr(int ks, int nt) { return kRcSplit ? ((ks + 7) / 8) * nt * 12 : ks * nt; }
 constexpr int rc_dfr(int no, int nt) { return kRcSplit ? ((no * (nt * 16 + 1) + 3) / 4) * 4 : no * (nt * 16 + 1); }
-// The density MLPs of the proposal levels stay on the fp32 MFMA in every build (mlp_layer_d, rc_dev_mlp.h: they run in
-// kernels with two or three waves per SIMD, where the split form hit an operand hazard -- see HAZARD there): their
+// The density MLPs of the proposal levels stay on the fp32 MFMA in every build (mlp_layer_d, rc_dev_mlp.h: with them in
+// the split form the two-wave kernel was unstable -- see INSTABILITY there): their
 // layers and dot blocks keep the fp32 geometry, and a stream that continues with split layers is padded to a whole piece.
 constexpr int rc_lfr32(int ks, int nt) { return ks * nt; }
 constexpr int rc_dfr32(int no, int nt) { return no * (nt * 16 + 1); }

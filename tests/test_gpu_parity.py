@@ -1017,8 +1017,9 @@ def test_transient_render_image_keys_and_shapes():
 @pytest.mark.parametrize("n,plan", [(4097, 1), (4097, 0), (25001, 1)])
 def test_repeated_launches_are_bitwise_stable_with_workgroups_out_of_phase(rc, n, plan):
     """More rays than one round of workgroups: those sharing a CU then run DIFFERENT phases of the kernel at the same time.
-    This is the screen that caught the operand hazard of the split-MFMA form with two waves per SIMD (csrc/rc_dev_mlp.h
-    HAZARD, tools/stress_repeat.py: one ray in a few hundred off by 1e-3 in most launches of a 4097-ray batch); the plans
+    This is the screen that caught the instability of the two-wave kernel with every layer in the split-MFMA form
+    (csrc/rc_dev_mlp.h INSTABILITY, tools/stress_repeat.py: one ray in a few hundred off by 1e-3 in most launches of a
+    4097-ray batch); the plans
     the library runs must come out bit for bit the same every time."""
     from nrc_amd import rc_ext
     assert rc_ext.mlp_arithmetic() in ("f32-mfma", "bf16x3-split")

@@ -1,7 +1,7 @@
 """Race screen of the cache pass: the same batch rendered many times on every launch plan must come out bit for bit the
 same, whatever the co-residence of workgroups (1024 rays: two workgroups per CU; 4097 / 25001: several rounds per CU and
 the level kernels with three waves per SIMD).  Prints one line per (plan, size): launches that differed from the first.
-The screen that found the operand hazard of the split-MFMA form (csrc/rc_dev_mlp.h): python tools/stress_repeat.py [launches]"""
+The screen that found the instability of the two-wave kernel under the split-MFMA form (csrc/rc_dev_mlp.h): python tools/stress_repeat.py [launches]"""
 import os
 import sys
 
