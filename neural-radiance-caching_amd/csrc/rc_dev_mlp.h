@@ -68,11 +68,23 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
 //     splits into a set follow the marker that retires it;
 //  3. behind a layer's last cell two flush MFMAs (16x16x32 into a 4-register sink that lives as long as the stream
 //     object and is never read) issue before the accumulators are read or the last operands are released.
+// (diagnostic switches: -DRC_RULE1=0 / -DRC_RULE2=0 / -DRC_RULE3=0 take a rule out; profiles/r04_split_mfma_hazard.txt, 4.)
+#ifndef RC_RULE1
+#define RC_RULE1 1
+#endif
+#ifndef RC_RULE2
+#define RC_RULE2 1
+#endif
+#ifndef RC_RULE3
+#define RC_RULE3 1
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split_keep(const u32x4& x) { asm volatile("" ::"v"(x)); }
-__device__ __forceinline__ void split_keep3(const u32x4 (&x)[3]) { asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(x[2])); }
+__device__ __forceinline__ void split_fence() { if constexpr (RC_RULE1 != 0) __builtin_amdgcn_sched_barrier(0); }
+__device__ __forceinline__ void split_keep(const u32x4& x) { if constexpr (RC_RULE2 != 0) asm volatile("" ::"v"(x)); }
+__device__ __forceinline__ void split_keep3(const u32x4 (&x)[3]) { if constexpr (RC_RULE2 != 0) asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(x[2])); }
 template <class WS>
 __device__ __forceinline__ void split_flush(const WS& w, const u32x4& any) {
+  if constexpr (RC_RULE3 == 0) return;
   __builtin_amdgcn_sched_barrier(0);
   w.sink = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, any), __builtin_bit_cast(bf16x8, any), w.sink, 0, 0, 0);
   w.sink = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, any), __builtin_bit_cast(bf16x8, any), w.sink, 0, 0, 0);
@@ -82,14 +94,14 @@ __device__ __forceinline__ void split_flush(const WS& w, const u32x4& any) {
 }
 // the six products of one (block, tile) cell, smallest first
 __device__ __forceinline__ void mfma_split6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16& acc) {
-  __builtin_amdgcn_sched_barrier(0);
+  split_fence();
   acc = mfma_bf16(a[2], b[0], acc);
   acc = mfma_bf16(a[0], b[2], acc);
   acc = mfma_bf16(a[1], b[1], acc);
   acc = mfma_bf16(a[1], b[0], acc);
   acc = mfma_bf16(a[0], b[1], acc);
   acc = mfma_bf16(a[0], b[0], acc);
-  __builtin_amdgcn_sched_barrier(0);
+  split_fence();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -144,7 +156,6 @@ template <int NF, int W = kWaves, int CH = kChunk>
 __device__ __forceinline__ void ws_advance(const WStream& w, int c) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-
   if ((c + 1) * CH < NF) ws_issue<NF, W, CH>(w, c + 1);
 }
 
@@ -299,11 +310,11 @@ __device__ __forceinline__ void mlp_bias_step(const WS& w, f32x16 (&acc)[NT]) {
       for (int p = 0; p < 3; ++p) a[t][p] = ws_read4<NF, W, CH>(w, FBASE + (t * 3 + p) * 4);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      __builtin_amdgcn_sched_barrier(0);
+      split_fence();
       acc[t] = mfma_bf16(a[t][2], b1, acc[t]);
       acc[t] = mfma_bf16(a[t][1], b1, acc[t]);
       acc[t] = mfma_bf16(a[t][0], b1, acc[t]);
-      __builtin_amdgcn_sched_barrier(0);
+      split_fence();
     }
     split_flush(w, b1);
 #pragma unroll
