@@ -60,6 +60,10 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
 //  * With the three rules below the full GPU suite and the repeat screen pass (129 tests, every plan and size bitwise
 //    stable), except for the two-wave kernel with EVERY layer split at 4097+ rays -- which is why the density MLPs stay
 //    fp32 (mlp_layer_d) and a split build does not run that kernel (rc_api.hip).
+//  * The common factor of every unstable launch is a wave of ANOTHER workgroup or kernel on the SIMD.  With the SIMD kept
+//    exclusive (split_exclusive_simd below: the wave allocates the whole register file) even the plain form passes the
+//    robustness tests (20 of 20, three runs; 5 of 20 fail without it).  That is the containment the product relies on;
+//    the rules stay as a second line.
 // So the rules are empirical: they are what separates the stable from the unstable form here, the mechanism is not
 // established.  They cost nothing measurable.
 //  1. the MFMAs of a cell issue back to back (scheduling barriers), nothing of the wave in between;
@@ -91,6 +95,13 @@ __device__ __forceinline__ void split_flush(const WS& w, const u32x4& any) {
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_nop 1" : "+v"(w.sink));
   __builtin_amdgcn_sched_barrier(0);
+}
+// A kernel that runs split-form layers keeps its SIMDs to itself: naming the last architectural and the last accumulation
+// register makes the wave allocate the whole 512-entry register file of its SIMD, so no wave of ANY other kernel or stream
+// can be placed beside it -- "one wave per SIMD" then holds under concurrent streams too, and a foreign wave on the SIMD
+// is the common factor of every unstable launch seen (INSTABILITY above).  Costs nothing when the kernel is alone.
+__device__ __forceinline__ void split_exclusive_simd() {
+  if constexpr (kRcSplit) asm volatile("" ::: "v255", "a255");
 }
 // the six products of one (block, tile) cell, smallest first
 __device__ __forceinline__ void mfma_split6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16& acc) {

@@ -67,6 +67,7 @@ __device__ __forceinline__ float density_level64(const WS& ws, float* act_wave, 
 // behind the cache pass (the material stage: its shading-point pick and the material-only composite).
 template <bool GRAD, bool FRONT = false, bool DIRECT = false, bool EXPORT = false>
 __global__ __launch_bounds__(kWaves * 64) void k_cache_fused(RcFusedArgs a) {
+  split_exclusive_simd();
   constexpr int NF = FRONT ? F_SH : NF_FUSED;
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_density_mlp(RcDensityMlpArgs a)
 
 __global__ __launch_bounds__(kWaves * 64) void k_cache_shader(RcShaderArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  split_exclusive_simd();
   constexpr int NF = ShaderFrags::COUNT;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
@@ -261,6 +262,7 @@ constexpr int kEnvRingFloats = 2 * kEnvChunk * 64;
 
 __global__ __launch_bounds__(kEnvWaves * 64) void k_envmap(RcEnvMapArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  split_exclusive_simd();
   constexpr int KS_IN = 15;   // 14 natural pairs of the 27 inputs (+1 zero pad) + bias
   constexpr int F_E0 = 0, F_E1 = F_E0 + rc_lfr(KS_IN, 8), F_E2 = F_E1 + rc_lfr(129, 8), F_EB = F_E2 + rc_lfr(129, 8),
                 F_EI = F_EB + rc_lfr(128, 4), F_EO = F_EI + rc_lfr(KS_IN, 4), NF = F_EO + rc_lfr(65, 1);

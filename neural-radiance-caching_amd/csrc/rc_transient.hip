@@ -64,6 +64,7 @@ __device__ __forceinline__ void stage16(float* act, int base, int h, const float
 }
 
 __global__ __launch_bounds__(kWaves * 64) void k_transient_shader(RcTransShaderArgs a) {
+  split_exclusive_simd();
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
@@ -443,6 +444,7 @@ __device__ __forceinline__ void tile_xw2(const WStream& w, int T, int nf, int c0
 
 __global__ __launch_bounds__(kWaves * 64) void k_transient_bins(RcTransBinsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  split_exclusive_simd();
 #ifdef RC_STAMPS
   const unsigned long long st_kernel_begin = __builtin_amdgcn_s_memtime();
 #endif
