@@ -331,7 +331,7 @@ def main():
     ap.add_argument("--plan", choices=("fused", "fused1", "staged"), default="fused",
                     help="fused: one launch per batch, two wavefronts per ray (rc_set_fused 1, default); fused1: the same with "
                          "one wavefront per ray (rc_set_fused 3, the round-1/2 kernel); staged: one launch per stage")
-    ap.add_argument("--runs", type=int, default=5,
+    ap.add_argument("--runs", type=int, default=9,
                     help="the timed region (--steps steps between two barriers) is repeated this many times in-process; "
                          "the MEDIAN run is reported as ms_per_step / value, all runs in config.ms_per_step_runs")
     ap.add_argument("--streams", type=int, default=1,
@@ -427,7 +427,9 @@ def main():
         torch.cuda.synchronize()
 
     # The timed region -- EXACTLY --steps steps between two (barrier + synchronize), MAX over the ranks -- is run
-    # --runs times back to back; the median run is the one reported (a 200-step region is 26 ms: one sample of a box).
+    # --runs times back to back (9); the median run is the one reported and all of them are listed in
+    # config.ms_per_step_runs (a 20-step region is 2.3 ms, a 200-step one 22 ms: the first regions after start-up still
+    # warm the MALL with the tables the batches touch -- 0.120, 0.118, 0.117, 0.115, 0.115 ... 0.109 ms per step).
     run_s = []
     for _ in range(max(1, args.runs)):
         barrier()
