@@ -237,7 +237,10 @@ def test_two_wave_fused_kernel_equals_the_one_wave_kernel(rc, n, jitter_seed):
     """rc_set_fused 1 (k_cache_fused_team: two wavefronts per ray, two rays per workgroup, csrc/rc_fused2.hip) against
     rc_set_fused 3 (k_cache_fused: one wavefront per ray): the same weight stream, the same MFMA order per accumulator,
     the same scans -- every output bitwise equal, odd ray counts (a workgroup with one live ray) included; with and
-    without requesting the analytic normals (the GRAD / non-GRAD instantiations)."""
+    without requesting the analytic normals (the GRAD / non-GRAD instantiations).
+    A library built with the split-form shader (rc_mlp_arithmetic() == 1, the default) runs the one-wave kernel for mode 1
+    as well: there the comparison is of that kernel with itself; it compares the two kernels in a
+    RC_SPLIT_MFMA=0 build (RC_HIP_LIBRARY) -- run that way in round 4: 129 passed."""
     rays = nrc_amd.synthetic_rays(n, seed=900 + n)
     rnd = None if jitter_seed is None else {"jitter": common.jitters(n, seed=jitter_seed)}
     for outputs in (None, ["rgb", "acc", "distance_median", "normals_pred"]):
